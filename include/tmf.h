@@ -1,0 +1,136 @@
+/*
+ * tmf.h - C ABI of libtmf.so, the MI355X (gfx950) engine behind
+ * teamoflow.mf.MatrixFactorization.fit / predict / recall_at_k / retrieve_user_recs.
+ *
+ * The reference (GitHubOfAndrew/TeAMOFlow v0.0.2) has no FFI of its own: its hot path is a
+ * sequence of TensorFlow eager ops issued from src/teamoflow/mf/matrix_factorization.py.  Each
+ * entry point below replaces one group of those call sites (cited per function, paths relative to
+ * the reference's src/teamoflow/mf/).  The Python host (teamoflow_amd/_lib.py) binds them with
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a BORROWED DEVICE pointer (owned by the caller, e.g. a torch tensor);
+ *     nothing is allocated, freed or synchronised inside the library;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the call returns
+ *     immediately (graph-capture safe);
+ *   - return value 0 = success, negative = TMF_E_* below; tmf_last_error() gives a thread-local
+ *     message for the last failing call on this thread;
+ *   - factor tables are fp32 row-major [rows, ld] with ld = tmf_padded_ld(n_components); the
+ *     columns [n_components, ld) are zero and stay zero;
+ *   - ids are int32, offsets into interaction / sample lists are int64.
+ */
+#ifndef TMF_H
+#define TMF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMF_VERSION 100 /* 0.1.0 */
+
+#define TMF_OK 0
+#define TMF_E_INVALID (-1)   /* bad argument (null pointer, unsupported rank, size mismatch) */
+#define TMF_E_LAUNCH (-2)    /* hipLaunch / runtime error, text in tmf_last_error() */
+#define TMF_E_UNSUPPORTED (-3)
+
+/* epilogue selector of the row passes */
+#define TMF_EPI_ADAM 0 /* out[row] = fresh-Adam(old[row], g[row])  (matrix_factorization.py:176) */
+#define TMF_EPI_GRAD 1 /* out[row] = g[row]  (multi-GPU: reduce-scatter first, then tmf_adam_fresh_rows) */
+
+int tmf_version(void);
+const char* tmf_last_error(void);
+
+/* Row length (in floats) the kernels use for an n_components-wide factor table: the next
+ * size that is 4 floats x a power-of-two number of lanes (<= 64), or a multiple of 256 above that.
+ * Returns 0 when n_components is outside [1, 1024]. */
+int tmf_padded_ld(int n_components);
+
+/* Scalars of one Keras Adam step at iteration 1 with zero moments, in fp32 - the reference builds
+ * a new optimizer every epoch (matrix_factorization.py:176), so this is the whole optimizer state.
+ *   alpha = lr*sqrt(1-b2)/(1-b1), one_minus_b1, one_minus_b2, eps = 1e-7 */
+typedef struct tmf_adam {
+    float alpha, one_minus_b1, one_minus_b2, eps;
+} tmf_adam;
+tmf_adam tmf_adam_fresh(float lr);
+
+/* A pass over the rows of one side (users or items), cut into segments of at most `chunk`
+ * list entries so that heavy rows are shared by several waves:
+ *   segment s covers entries [rowptr[seg_row[s]] + seg_chunk[s]*chunk, ... + chunk) of its row;
+ *   seg_slab[s] = -1 when the row has a single segment (the epilogue runs in the pass itself),
+ *   otherwise the slot of `slab` [n_slab, ld] that receives this segment's partial gradient; rows with
+ *   several segments are finished by tmf_combine_rows in slot order (deterministic, atomics-free). */
+typedef struct tmf_segments {
+    const int64_t* rowptr;    /* [rows + 1] */
+    const int32_t* seg_row;   /* [nseg] */
+    const int32_t* seg_chunk; /* [nseg] */
+    const int32_t* seg_slab;  /* [nseg] */
+    int64_t nseg;
+    int32_t chunk;
+} tmf_segments;
+
+/* K1+K2 / K3: one side of an MSE epoch (loss_graphs.py:47-52 forward; tape.gradient
+ * matrix_factorization.py:170-171; Adam :176) evaluated sparsely:
+ *   for every entry k of row i:  p = <X_old[i], Y_old[other[k]]>, e = val[k] - p,
+ *   loss += e*e, g[i] += (-2e) * Y_old[other[k]]; then the epilogue `epi` writes X_out[i].
+ * Call once with (X=U, Y=V, CSR by user) and once with (X=V, Y=U, CSC by item); both read the
+ * PRE-update tables.  loss_part (optional, [nseg]) receives the per-segment sum of e*e. */
+int tmf_mse_pass_f32(const tmf_segments* seg, const int32_t* other, const float* val,
+                     const float* X_old, const float* Y_old, float* X_out, float* slab,
+                     float* loss_part, int n_components, int epi, tmf_adam adam, void* stream);
+
+/* Weighted row-gather-sum pass (item side of WMRB, matrix_factorization.py:170-171 through
+ * loss_graphs.py:80-88):  g[i] = sum over entries e of row i of  wbuf[ent_w[e]] * T[ent_row[e]]
+ * (entries with weight exactly 0 are skipped), then the epilogue writes X_out[i]. */
+int tmf_wsum_pass_f32(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w,
+                      const float* wbuf, const float* T, const float* X_old, float* X_out,
+                      float* slab, int n_components, int epi, tmf_adam adam, void* stream);
+
+/* Finishes the rows that tmf_*_pass cut into several segments: g[row] = sum of its slab slots
+ * [slab_beg[i], slab_beg[i+1]) in order, then the epilogue. */
+int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
+                         const float* slab, const float* X_old, float* X_out, int n_components,
+                         int epi, tmf_adam adam, void* stream);
+
+/* K4+K5: user side of a WMRB epoch for users [0, n_users) (matrix_factorization.py:153-154 sampled
+ * and serial scores, loss_graphs.py:74-88, gradient w.r.t. U, Adam :176).
+ *   R [n_users, S] int32 static negative table (utils.py:20), c = n_items / n_samples (ctor ints);
+ *   writes delta [nnz] (d loss / d p_k, 0 for non-positive entries), D [n_users, S],
+ *   loss_part [n_users] (sum of log(1+M_k) over the user's positives), pos_part [n_users] (#positives),
+ *   and U_out via the epilogue. */
+int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                           const int32_t* R, int32_t n_users, int32_t S, float c,
+                           const float* U_old, const float* V_old, float* U_out, float* delta,
+                           float* D, float* loss_part, float* pos_part, int n_components, int epi,
+                           tmf_adam adam, void* stream);
+
+/* K6 standalone: W[rows] = fresh-Adam(W[rows], G[rows]) in place over n_rows x ld floats. */
+int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,
+                            tmf_adam adam, void* stream);
+
+/* Deterministic sum of `n` floats into out[0] (fp64 accumulate, fixed order) - the reduce_mean
+ * numerator of matrix_factorization.py:179. */
+int tmf_sum_f32(const float* x, int64_t n, double* out, void* stream);
+
+/* utils.py:94-105 gather_matrix_indices: out[i, c] = X[i, idx[i, c]];  X [rows, cols] fp32,
+ * idx [rows, k] int64. */
+int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, float* out, int64_t rows,
+                             int64_t cols, int64_t k, void* stream);
+
+/* K7: C[m, n] = A[m, :r] . B[n, :r]^T in exact fp32 on the f32 MFMA (matrix_factorization.py:149,195).
+ * lda / ldb / ldc in floats. */
+int tmf_predict_gemm_f32(const float* A, const float* B, float* C, int64_t m, int64_t n, int r,
+                         int64_t lda, int64_t ldb, int64_t ldc, void* stream);
+
+/* K8: row-wise top-k of X [rows, cols] ordered (value desc, index asc) - tf.math.top_k's contract
+ * (matrix_factorization.py:245,429-438).  clamp_negatives != 0 first maps x <= 0 to 0.0
+ * (matrix_factorization.py:237).  out_idx [rows, k] int32, out_val optional [rows, k]. */
+int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, int k,
+                        int clamp_negatives, int32_t* out_idx, float* out_val, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMF_H */

@@ -1,0 +1,191 @@
+"""Host side of the sparse training path: index structures built once per ``fit`` and the per-epoch
+launch sequence.  Everything numeric runs in libtmf.so (HIP); torch is used for device memory,
+streams and the one-off index preparation (sort / bincount / cumsum).
+
+What replaces what (reference paths under /root/reference/src/teamoflow/mf/):
+  epoch_mse   <- matrix_factorization.py:130-176 with MSELoss  (loss_graphs.py:47-52)
+  epoch_wmrb  <- matrix_factorization.py:130-176 with WMRBLoss (loss_graphs.py:74-88, utils.py:94-105)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+DEFAULT_CHUNK = 1024  # list entries per segment (heavy rows are cut into several segments)
+
+
+def _excl_cumsum(x):
+    out = torch.zeros(x.numel() + 1, dtype=torch.int64, device=x.device)
+    torch.cumsum(x, 0, out=out[1:])
+    return out
+
+
+class SegmentTable:
+    """Rows of one side cut into segments of <= chunk entries (see include/tmf.h, tmf_segments)."""
+
+    def __init__(self, rowptr, chunk=DEFAULT_CHUNK):
+        dev = rowptr.device
+        rows = rowptr.numel() - 1
+        lens = rowptr[1:] - rowptr[:-1]
+        nch = torch.clamp((lens + (chunk - 1)) // chunk, min=1)
+        nseg = int(nch.sum())
+        seg_first = _excl_cumsum(nch)
+        ar = torch.arange(rows, device=dev)
+        seg_row = torch.repeat_interleave(ar, nch, output_size=nseg)
+        seg_chunk = torch.arange(nseg, device=dev) - seg_first[seg_row]
+        multi = nch > 1
+        slab_beg = _excl_cumsum(nch * multi)
+        seg_slab = torch.where(multi[seg_row], slab_beg[seg_row] + seg_chunk, torch.full_like(seg_chunk, -1))
+        long_rows = torch.nonzero(multi).flatten()
+        self.rows, self.chunk, self.nseg = rows, int(chunk), nseg
+        self.rowptr = rowptr.contiguous()
+        self.seg_row = seg_row.to(torch.int32)
+        self.seg_chunk = seg_chunk.to(torch.int32)
+        self.seg_slab = seg_slab.to(torch.int32)
+        self.long_rows = long_rows.to(torch.int32)
+        self.n_long = int(long_rows.numel())
+        self.n_slab = int(slab_beg[-1])
+        self.long_slab_beg = torch.cat([slab_beg[long_rows], slab_beg[-1:]]).contiguous()
+        self._c = None
+
+    def cstruct(self):
+        if self._c is None:
+            self._c = _lib.Segments(self.rowptr.data_ptr(), self.seg_row.data_ptr(), self.seg_chunk.data_ptr(),
+                                    self.seg_slab.data_ptr(), self.nseg, self.chunk)
+        return ctypes.byref(self._c)
+
+
+class InteractionPlan:
+    """CSR-by-user and CSC-by-item views of the interactions (values duplicated in both orders)."""
+
+    def __init__(self, indices, values, n_users, n_items, chunk=DEFAULT_CHUNK):
+        dev = indices.device
+        u = indices[:, 0].contiguous()
+        j = indices[:, 1].contiguous()
+        nnz = u.numel()
+        if nnz and (int(u.min()) < 0 or int(u.max()) >= n_users or int(j.min()) < 0 or int(j.max()) >= n_items):
+            raise IndexError('interaction indices outside dense_shape')
+        values = values.to(torch.float32)
+        if nnz > 1 and not bool((u[1:] >= u[:-1]).all()):
+            perm = torch.sort(u, stable=True)[1]
+            u, j, values = u[perm], j[perm], values[perm]
+        self.nnz, self.n_users, self.n_items = nnz, n_users, n_items
+        self.rowptr_u = _excl_cumsum(torch.bincount(u, minlength=n_users))
+        self.col_u = j.to(torch.int32)
+        self.val_u = values.contiguous()
+        perm_c = torch.sort(j, stable=True)[1]
+        self.rowptr_i = _excl_cumsum(torch.bincount(j, minlength=n_items))
+        self.row_i = u[perm_c].to(torch.int32)
+        self.val_i = values[perm_c].contiguous()
+        self.csc_to_csr = perm_c
+        self.seg_u = SegmentTable(self.rowptr_u, chunk)
+        self.seg_i = SegmentTable(self.rowptr_i, chunk)
+        self.n_pos = int((values > 0).sum())
+        self.user_ids = u  # int64, CSR order (kept for the WMRB entry lists)
+
+
+class WmrbPlan:
+    """Per-item entry lists of the WMRB item-side gradient:
+    positives of the item (weight delta_k) followed by the (user, sample-slot) pairs whose static
+    negative is the item (weight D[u, s]); weights live in one buffer wbuf = [delta | D]."""
+
+    def __init__(self, plan, R, chunk=DEFAULT_CHUNK):
+        dev = R.device
+        m, S = R.shape
+        nnz = plan.nnz
+        pos_k = torch.nonzero(plan.val_u > 0).flatten()  # CSR positions of the positives
+        P = pos_k.numel()
+        keys = torch.cat([plan.col_u[pos_k], R.reshape(-1)])
+        order = torch.sort(keys, stable=True)[1]
+        del keys
+        is_pos = order < P
+        e = order - P  # sample entry id u * S + s (negative for positives, unused there)
+        if P:
+            pk = pos_k[torch.clamp(order, max=P - 1)]
+            ent_row = torch.where(is_pos, plan.user_ids[pk], e // S)
+            ent_w = torch.where(is_pos, pk, nnz + e)
+        else:
+            ent_row, ent_w = e // S, nnz + e
+        counts = torch.bincount(plan.col_u[pos_k].to(torch.int64), minlength=plan.n_items) + \
+            torch.bincount(R.reshape(-1).to(torch.int64), minlength=plan.n_items)
+        self.S = S
+        self.R = R
+        self.ent_row = ent_row.to(torch.int32).contiguous()
+        self.ent_w = ent_w.to(torch.int64).contiguous()
+        self.rowptr_e = _excl_cumsum(counts)
+        self.seg_e = SegmentTable(self.rowptr_e, chunk)
+        self.wbuf = torch.zeros(nnz + m * S, dtype=torch.float32, device=dev)
+        self.delta = self.wbuf[:nnz]
+        self.D = self.wbuf[nnz:].view(m, S)
+
+
+class TrainState:
+    """Double-buffered factor tables [rows, ld] and the scratch the passes need."""
+
+    def __init__(self, U0, V0, plan, n_components, wplan=None):
+        dev = plan.col_u.device
+        self.r = int(n_components)
+        self.ld = _lib.padded_ld(self.r)
+        self.U = self._pad(U0, dev)
+        self.V = self._pad(V0, dev)
+        self.U_nxt = torch.empty_like(self.U)
+        self.V_nxt = torch.empty_like(self.V)
+        self.plan, self.wplan = plan, wplan
+        n_slab = max(plan.seg_u.n_slab, plan.seg_i.n_slab, wplan.seg_e.n_slab if wplan else 0, 1)
+        self.slab = torch.empty(n_slab, self.ld, dtype=torch.float32, device=dev)
+        n_part = max(plan.seg_u.nseg, plan.n_users, 1)
+        self.loss_part = torch.zeros(n_part, dtype=torch.float32, device=dev)
+
+    def _pad(self, W, dev):
+        W = torch.as_tensor(W).detach().to(device=dev, dtype=torch.float32)
+        out = torch.zeros(W.shape[0], self.ld, dtype=torch.float32, device=dev)
+        out[:, :self.r] = W
+        return out
+
+    def swap(self):
+        self.U, self.U_nxt = self.U_nxt, self.U
+        self.V, self.V_nxt = self.V_nxt, self.V
+
+
+def _row_pass_finish(lib, seg, slab, X_old, X_out, r, epi, adam, stream):
+    if seg.n_long:
+        _lib.check(lib.tmf_combine_rows_f32(_lib.ptr(seg.long_rows), _lib.ptr(seg.long_slab_beg), seg.n_long,
+                                            _lib.ptr(slab), _lib.ptr(X_old), _lib.ptr(X_out), r, epi, adam, stream), lib)
+
+
+def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None):
+    """One MSE epoch: user pass (+loss), item pass; both read the pre-update tables.
+    loss_out: 1-element fp64 device tensor receiving sum_k (a_k - p_k)^2.
+    item_epi=EPI_GRAD writes the raw item gradient into item_out (multi-GPU)."""
+    lib, p, r = _lib.get(), st.plan, st.r
+    s = _lib.stream_ptr()
+    _lib.check(lib.tmf_mse_pass_f32(p.seg_u.cstruct(), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.U),
+                                    _lib.ptr(st.V), _lib.ptr(st.U_nxt), _lib.ptr(st.slab), _lib.ptr(st.loss_part),
+                                    r, _lib.EPI_ADAM, adam, s), lib)
+    _row_pass_finish(lib, p.seg_u, st.slab, st.U, st.U_nxt, r, _lib.EPI_ADAM, adam, s)
+    _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.seg_u.nseg, _lib.ptr(loss_out), s), lib)
+    V_out = st.V_nxt if item_out is None else item_out
+    _lib.check(lib.tmf_mse_pass_f32(p.seg_i.cstruct(), _lib.ptr(p.row_i), _lib.ptr(p.val_i), _lib.ptr(st.V),
+                                    _lib.ptr(st.U), _lib.ptr(V_out), _lib.ptr(st.slab), None, r, item_epi, adam, s), lib)
+    _row_pass_finish(lib, p.seg_i, st.slab, st.V, V_out, r, item_epi, adam, s)
+
+
+def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None):
+    """One WMRB epoch.  loss_out receives sum over positives of log(1 + M_k)."""
+    lib, p, w, r = _lib.get(), st.plan, st.wplan, st.r
+    s = _lib.stream_ptr()
+    _lib.check(lib.tmf_wmrb_user_pass_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
+                                          p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
+                                          _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None, r,
+                                          _lib.EPI_ADAM, adam, s), lib)
+    _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)
+    V_out = st.V_nxt if item_out is None else item_out
+    _lib.check(lib.tmf_wsum_pass_f32(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf),
+                                     _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(V_out), _lib.ptr(st.slab), r, item_epi,
+                                     adam, s), lib)
+    _row_pass_finish(lib, w.seg_e, st.slab, st.V, V_out, r, item_epi, adam, s)
+
+
+def adam_constants(lr):
+    return _lib.load_library().tmf_adam_fresh(float(lr))

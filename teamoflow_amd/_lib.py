@@ -1,0 +1,127 @@
+"""ctypes binding of libtmf.so (C ABI in include/tmf.h).
+
+The engine has no CPU implementation: every entry point needs the gfx950 code object and a
+visible MI355X.  ``get()`` raises ``EngineUnavailable`` loudly instead of falling back to anything.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('TMF_LIB', os.path.join(_HERE, 'libtmf.so'))
+CSRC = os.path.join(_HERE, 'csrc')
+
+EPI_ADAM, EPI_GRAD = 0, 1
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Adam(ctypes.Structure):
+    _fields_ = [('alpha', ctypes.c_float), ('one_minus_b1', ctypes.c_float), ('one_minus_b2', ctypes.c_float),
+                ('eps', ctypes.c_float)]
+
+
+class Segments(ctypes.Structure):
+    _fields_ = [('rowptr', ctypes.c_void_p), ('seg_row', ctypes.c_void_p), ('seg_chunk', ctypes.c_void_p),
+                ('seg_slab', ctypes.c_void_p), ('nseg', ctypes.c_int64), ('chunk', ctypes.c_int32)]
+
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_SEG = ctypes.POINTER(Segments)
+
+# name -> (restype, argtypes); must list every symbol include/tmf.h declares (tests check this)
+SIGNATURES = {
+    'tmf_version': (_I, []),
+    'tmf_last_error': (ctypes.c_char_p, []),
+    'tmf_padded_ld': (_I, [_I]),
+    'tmf_adam_fresh': (Adam, [_F]),
+    'tmf_mse_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_wsum_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P,
+                                     _I, _I, Adam, _P]),
+    'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
+    'tmf_sum_f32': (_I, [_P, _L, _P, _P]),
+    'tmf_gather_rows_cols_f32': (_I, [_P, _P, _P, _L, _L, _L, _P]),
+    'tmf_predict_gemm_f32': (_I, [_P, _P, _P, _L, _L, _I, _L, _L, _L, _P]),
+    'tmf_topk_stable_f32': (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile libtmf.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(['make', '-C', CSRC, 'clean'], check=True, capture_output=not verbose)
+    subprocess.run(['make', '-C', CSRC, '-j4'], check=True, capture_output=not verbose)
+    return LIB_PATH
+
+
+def load_library():
+    """dlopen libtmf.so and attach the signatures.  Needs no GPU (used by the CPU symbol test).
+    torch is imported first on purpose: its bundled libamdhip64 (SONAME libamdhip64.so.7) is then
+    already in the process and libtmf's DT_NEEDED entry resolves to that same runtime, so torch's
+    streams and allocations are valid inside the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(f'{LIB_PATH} not found - run `python -c "import __graft_entry__ as g; g.build()"` '
+                                f'or `make -C {CSRC}`')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.tmf_version() < 100:
+        raise EngineUnavailable('libtmf.so is older than this package')
+    _lib = lib
+    return lib
+
+
+def get():
+    """The library, ready to launch on the current torch device.  Raises if there is no GPU."""
+    if not torch.cuda.is_available():
+        raise EngineUnavailable('teamoflow_amd needs an MI355X: torch.cuda.is_available() is False and the '
+                                'engine has no CPU fallback')
+    return load_library()
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load_library()
+        raise EngineError(f'libtmf error {rc}: {lib.tmf_last_error().decode()}')
+
+
+def padded_ld(n_components):
+    """Mirror of tmf_padded_ld, usable without loading the library."""
+    r = int(n_components)
+    if r < 1 or r > 1024:
+        raise ValueError(f'n_components={r} outside the supported range [1, 1024]')
+    if r <= 256:
+        lanes, g = (r + 3) // 4, 1
+        while g < lanes:
+            g *= 2
+        return 4 * g
+    nv = (r + 255) // 256
+    if nv == 3:
+        nv = 4
+    return 256 * nv

@@ -1,0 +1,82 @@
+"""Tensor-level wrappers over the predict / ranking entry points of libtmf.so."""
+import torch
+
+from . import _lib
+
+
+def _cuda(t, dtype=None):
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    _lib.get()  # raises EngineUnavailable without a GPU: there is no CPU path
+    if not t.is_cuda:
+        t = t.cuda()
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t
+
+
+def _gemm_operand(t):
+    """[rows, r] fp32 tensor -> (tensor kept alive, rows, r, ld) with 16-byte aligned rows."""
+    t = _cuda(t, torch.float32).detach()
+    rows, r = t.shape
+    ok = t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= r and t.data_ptr() % 16 == 0
+    if not ok:
+        ld = (r + 3) // 4 * 4
+        p = torch.zeros(rows, ld, dtype=torch.float32, device=t.device)
+        p[:, :r] = t
+        t = p[:, :r]
+    return t, rows, r, t.stride(0)
+
+
+def predict_gemm(user_embedding, item_embedding, out=None):
+    """user_embedding [m, r] @ item_embedding [n, r]^T -> [m, n] fp32 (exact-fp32 MFMA)."""
+    lib = _lib.get()
+    A, m, r, lda = _gemm_operand(user_embedding)
+    B, n, rb, ldb = _gemm_operand(item_embedding)
+    if r != rb:
+        raise ValueError(f'embedding widths differ: {r} vs {rb}')
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=A.device)
+    _lib.check(lib.tmf_predict_gemm_f32(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), m, n, r, lda, ldb, out.stride(0),
+                                        _lib.stream_ptr()), lib)
+    return out
+
+
+def topk_stable(x, k, clamp_negatives=False, return_values=False):
+    """Row-wise top-k indices (int32) ordered like tf.math.top_k: value desc, ties -> lower index."""
+    lib = _lib.get()
+    x = _cuda(x, torch.float32)
+    squeeze = x.dim() == 1
+    if squeeze:
+        x = x[None, :]
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, cols = x.shape
+    k = int(k)
+    if not 1 <= k <= cols:
+        raise ValueError(f'k={k} must be in [1, {cols}]')  # tf.math.top_k raises for k > last dim
+    idx = torch.empty(rows, k, dtype=torch.int32, device=x.device)
+    vals = torch.empty(rows, k, dtype=torch.float32, device=x.device) if return_values else None
+    _lib.check(lib.tmf_topk_stable_f32(_lib.ptr(x), rows, cols, x.stride(0), k, int(bool(clamp_negatives)),
+                                       _lib.ptr(idx), _lib.ptr(vals), _lib.stream_ptr()), lib)
+    if squeeze:
+        idx = idx[0]
+        vals = vals[0] if return_values else None
+    return (vals, idx) if return_values else idx
+
+
+def gather_rows_cols(x, idx):
+    """out[i, c] = x[i, idx[i, c]]."""
+    lib = _lib.get()
+    x = _cuda(x, torch.float32).contiguous()
+    idx = _cuda(idx, torch.int64).contiguous()
+    rows, cols = x.shape
+    if idx.shape[0] != rows:
+        raise ValueError('index_arr must have the same number of rows as input_arr')
+    k = idx.shape[1]
+    if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= cols):
+        raise IndexError('column index out of range')
+    out = torch.empty(rows, k, dtype=torch.float32, device=x.device)
+    _lib.check(lib.tmf_gather_rows_cols_f32(_lib.ptr(x), _lib.ptr(idx), _lib.ptr(out), rows, cols, k,
+                                            _lib.stream_ptr()), lib)
+    return out

@@ -1,0 +1,191 @@
+// Shared device helpers for libtmf (gfx950 only: 64-lane waves, 16-byte lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tmf.h"
+
+namespace tmf {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define TMF_REQUIRE(cond, ...)             \
+    do {                                   \
+        if (!(cond)) {                     \
+            tmf::set_error(__VA_ARGS__);   \
+            return TMF_E_INVALID;          \
+        }                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Row geometry.  A factor row of `ld` floats is read by a GROUP of G lanes, NV float4 per lane:
+// lane g of the group holds floats [4*(g + G*v), 4*(g + G*v) + 4) for v < NV, so every load
+// instruction of a group is one contiguous 16*G-byte piece of the row.  64/G groups per wave work
+// on different list entries at once.
+// ---------------------------------------------------------------------------------------------
+struct RowGeom {
+    int G, NV, ld;
+};
+inline RowGeom row_geom(int r) {
+    RowGeom g{0, 0, 0};
+    if (r < 1 || r > 1024) return g;
+    if (r <= 256) {
+        int lanes = (r + 3) / 4, G = 1;
+        while (G < lanes) G <<= 1;
+        g = {G, 1, 4 * G};
+    } else {
+        int NV = (r + 255) / 256;
+        if (NV == 3) NV = 4;
+        g = {64, NV, 256 * NV};
+    }
+    return g;
+}
+
+// Dispatch a callable templated on <G, NV> for the geometry of rank r.
+#define TMF_DISPATCH_GEOM(geom, CALL)                       \
+    switch ((geom).G * 8 + (geom).NV) {                     \
+        case 1 * 8 + 1: { CALL(1, 1); } break;              \
+        case 2 * 8 + 1: { CALL(2, 1); } break;              \
+        case 4 * 8 + 1: { CALL(4, 1); } break;              \
+        case 8 * 8 + 1: { CALL(8, 1); } break;              \
+        case 16 * 8 + 1: { CALL(16, 1); } break;            \
+        case 32 * 8 + 1: { CALL(32, 1); } break;            \
+        case 64 * 8 + 1: { CALL(64, 1); } break;            \
+        case 64 * 8 + 2: { CALL(64, 2); } break;            \
+        case 64 * 8 + 4: { CALL(64, 4); } break;            \
+        default: tmf::set_error("unsupported n_components"); \
+            return TMF_E_UNSUPPORTED;                       \
+    }
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+struct Frag {
+    float4 v[NV];
+};
+
+template <int G, int NV>
+__device__ __forceinline__ void load_row(Frag<NV>& f, const float* __restrict__ T, int64_t row, int g) {
+    const float4* p = reinterpret_cast<const float4*>(T + row * (int64_t)(4 * G * NV)) + g;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) f.v[v] = p[G * v];
+}
+
+template <int G, int NV>
+__device__ __forceinline__ void store_row(const Frag<NV>& f, float* __restrict__ T, int64_t row, int g) {
+    float4* p = reinterpret_cast<float4*>(T + row * (int64_t)(4 * G * NV)) + g;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[G * v] = f.v[v];
+}
+
+template <int NV>
+__device__ __forceinline__ void zero(Frag<NV>& f) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) f.v[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int NV>
+__device__ __forceinline__ float dot_partial(const Frag<NV>& a, const Frag<NV>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        s = fmaf(a.v[v].x, b.v[v].x, s);
+        s = fmaf(a.v[v].y, b.v[v].y, s);
+        s = fmaf(a.v[v].z, b.v[v].z, s);
+        s = fmaf(a.v[v].w, b.v[v].w, s);
+    }
+    return s;
+}
+
+template <int NV>
+__device__ __forceinline__ void axpy(Frag<NV>& acc, float w, const Frag<NV>& x) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        acc.v[v].x = fmaf(w, x.v[v].x, acc.v[v].x);
+        acc.v[v].y = fmaf(w, x.v[v].y, acc.v[v].y);
+        acc.v[v].z = fmaf(w, x.v[v].z, acc.v[v].z);
+        acc.v[v].w = fmaf(w, x.v[v].w, acc.v[v].w);
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void add(Frag<NV>& acc, const Frag<NV>& x) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        acc.v[v].x += x.v[v].x;
+        acc.v[v].y += x.v[v].y;
+        acc.v[v].z += x.v[v].z;
+        acc.v[v].w += x.v[v].w;
+    }
+}
+
+// Sum over the G lanes of a group (lanes [G*k, G*k+G)); every lane of the group ends with the
+// same bits (x+y == y+x), so the value can be used as a per-entry weight by all of them.
+template <int G>
+__device__ __forceinline__ float group_allsum(float v) {
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum of a per-lane value over the 64/G groups of a wave (same lane-in-group across groups).
+template <int G>
+__device__ __forceinline__ float across_groups_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= G; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int G, int NV>
+__device__ __forceinline__ void across_groups_sum(Frag<NV>& f) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        f.v[v].x = across_groups_sum<G>(f.v[v].x);
+        f.v[v].y = across_groups_sum<G>(f.v[v].y);
+        f.v[v].z = across_groups_sum<G>(f.v[v].z);
+        f.v[v].w = across_groups_sum<G>(f.v[v].w);
+    }
+}
+
+// Fresh Keras-Adam step (t = 1, zero moments), unsimplified fp32 op sequence of SURVEY.md A.1:
+//   m = (g - 0)(1-b1); v = (g*g - 0)(1-b2); w -= (m*alpha)/(sqrt(v)+eps)
+// __fsqrt_rn / __fdiv_rn keep IEEE rounding whatever -ffast-math-like flags the build uses.
+__device__ __forceinline__ float adam_fresh(float w, float g, const tmf_adam a) {
+    const float m = g * a.one_minus_b1;
+    const float v = (g * g) * a.one_minus_b2;
+    return w - __fdiv_rn(m * a.alpha, __fsqrt_rn(v) + a.eps);
+}
+
+template <int NV>
+__device__ __forceinline__ void adam_fresh(Frag<NV>& w, const Frag<NV>& g, const tmf_adam a) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        w.v[v].x = adam_fresh(w.v[v].x, g.v[v].x, a);
+        w.v[v].y = adam_fresh(w.v[v].y, g.v[v].y, a);
+        w.v[v].z = adam_fresh(w.v[v].z, g.v[v].z, a);
+        w.v[v].w = adam_fresh(w.v[v].w, g.v[v].w, a);
+    }
+}
+
+// Epilogue shared by every row pass: lanes of group 0 write the row.
+template <int G, int NV>
+__device__ __forceinline__ void row_epilogue(const Frag<NV>& g, const float* __restrict__ X_old,
+                                             float* __restrict__ X_out, int64_t row, int lane_in_group,
+                                             int epi, const tmf_adam adam) {
+    if (epi == TMF_EPI_GRAD) {
+        store_row<G, NV>(g, X_out, row, lane_in_group);
+    } else {
+        Frag<NV> w;
+        load_row<G, NV>(w, X_old, row, lane_in_group);
+        adam_fresh<NV>(w, g, adam);
+        store_row<G, NV>(w, X_out, row, lane_in_group);
+    }
+}
+
+}  // namespace tmf

@@ -1,0 +1,283 @@
+// K7 predict GEMM on the exact-fp32 MFMA, K8 tie-stable row top-k, and gather_matrix_indices.
+#include <math.h>
+
+#include "tmf_common.h"
+
+namespace tmf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// C[m, n] = A[m, :K] . B[n, :K]^T   (both operands K-contiguous: U and V as stored).
+// 256 threads = 4 waves in a 2x2 grid; each wave owns a 64x64 block as 2x2 v_mfma_f32_32x32x2_f32
+// tiles (64 accumulator registers).  A and B panels are staged k-major in LDS ([k][row], row
+// stride BM+1) so the MFMA operand read (lane l -> row l&31, k l>>5) is conflict-free.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 1;
+
+__global__ __launch_bounds__(256) void k_predict_gemm(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ C, int64_t m, int64_t n, int K,
+                                                      int64_t lda, int64_t ldb, int64_t ldc, int tiles_n) {
+    __shared__ float As[BK * LDT];
+    __shared__ float Bs[BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int64_t row0 = tile_m * BM, col0 = tile_n * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // staging map: thread -> (row = tid / 4 + 64 * h, k-quad = tid % 4), float4 along k
+    const int srow = tid >> 2, skq = tid & 3;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = srow + 64 * h;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            const int kk = k0 + 4 * skq;
+            if (row0 + r < m) {
+                const float* p = A + (row0 + r) * lda + kk;
+                if (kk + 3 < K) a = *reinterpret_cast<const float4*>(p);
+                else { if (kk < K) a.x = p[0]; if (kk + 1 < K) a.y = p[1]; if (kk + 2 < K) a.z = p[2]; }
+            }
+            if (col0 + r < n) {
+                const float* p = B + (col0 + r) * ldb + kk;
+                if (kk + 3 < K) b = *reinterpret_cast<const float4*>(p);
+                else { if (kk < K) b.x = p[0]; if (kk + 1 < K) b.y = p[1]; if (kk + 2 < K) b.z = p[2]; }
+            }
+            As[(4 * skq + 0) * LDT + r] = a.x; As[(4 * skq + 1) * LDT + r] = a.y;
+            As[(4 * skq + 2) * LDT + r] = a.z; As[(4 * skq + 3) * LDT + r] = a.w;
+            Bs[(4 * skq + 0) * LDT + r] = b.x; Bs[(4 * skq + 1) * LDT + r] = b.y;
+            Bs[(4 * skq + 2) * LDT + r] = b.z; Bs[(4 * skq + 3) * LDT + r] = b.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 2) {
+            const int kl = ks + (lane >> 5), rl = lane & 31;
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[kl * LDT + wr * 64 + i * 32 + rl];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[kl * LDT + wc * 64 + j * 32 + rl];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map of the 32x32 tile: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t c = col0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t r = row0 + wr * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                if (r < m && c < n) C[r * ldc + c] = acc[i][j][q];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row top-k, ordered (value desc, index asc).  One wave per row.  Each lane keeps its own k best
+// (sorted, in a lane-private LDS column) over the columns it scans in increasing index order - a
+// later equal value never displaces an earlier one - then the wave extracts the global k best by
+// k rounds of arg-max over the lanes' heads under the same total order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool before(float va, int ia, float vb, int ib) {
+    return (va > vb) || (va == vb && ia < ib);
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(64) void k_topk_small(const float* __restrict__ X, int64_t cols, int64_t ldx, int k,
+                                                   int clamp, int32_t* __restrict__ out_idx,
+                                                   float* __restrict__ out_val) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* lv = reinterpret_cast<float*>(smem_raw);        // [k][64]
+    int* li = reinterpret_cast<int*>(lv + (size_t)k * 64); // [k][64]
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const float* x = X + row * ldx;
+    for (int j = 0; j < k; ++j) {
+        lv[j * 64 + lane] = -INFINITY;
+        li[j * 64 + lane] = 0x7fffffff;
+    }
+    float thr = -INFINITY;  // lane's current k-th best
+    auto offer = [&](float v, int idx) {
+        if (clamp) v = (v > 0.f) ? v : 0.f;
+        if (v > thr) {
+            int j = k - 1;
+            while (j > 0 && lv[(j - 1) * 64 + lane] < v) {
+                lv[j * 64 + lane] = lv[(j - 1) * 64 + lane];
+                li[j * 64 + lane] = li[(j - 1) * 64 + lane];
+                --j;
+            }
+            lv[j * 64 + lane] = v;
+            li[j * 64 + lane] = idx;
+            thr = lv[(k - 1) * 64 + lane];
+        }
+    };
+    if (VEC4) {
+        const int64_t n4 = cols / 4;
+        for (int64_t t = lane; t < n4; t += 64) {
+            const float4 q = reinterpret_cast<const float4*>(x)[t];
+            const int b = (int)(4 * t);
+            offer(q.x, b); offer(q.y, b + 1); offer(q.z, b + 2); offer(q.w, b + 3);
+        }
+        // the tail (cols % 4) comes after every vector element in index order
+        for (int64_t t = 4 * n4 + lane; t < cols; t += 64) offer(x[t], (int)t);
+    } else {
+        for (int64_t t = lane; t < cols; t += 64) offer(x[t], (int)t);
+    }
+    // extraction
+    int head = 0;
+    float hv = lv[lane];
+    int hi = li[lane];
+    for (int r = 0; r < k; ++r) {
+        float bv = hv;
+        int bi = hi;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            out_idx[row * k + r] = bi;
+            if (out_val) out_val[row * k + r] = bv;
+        }
+        if (hi == bi && head < k) {  // the winner pops its head (indices are unique)
+            ++head;
+            if (head < k) { hv = lv[head * 64 + lane]; hi = li[head * 64 + lane]; }
+            else { hv = -INFINITY; hi = 0x7fffffff; }
+        }
+    }
+}
+
+// Full ranking (k > 64): one block per row, bitonic sort of (value, index) in LDS under the same
+// total order.  cols padded to a power of two with (-inf, INT_MAX).
+__global__ __launch_bounds__(1024) void k_sort_rows(const float* __restrict__ X, int64_t cols, int64_t ldx, int k,
+                                                    int clamp, int npow2, int32_t* __restrict__ out_idx,
+                                                    float* __restrict__ out_val) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sv = reinterpret_cast<float*>(smem_raw);
+    int* si = reinterpret_cast<int*>(sv + npow2);
+    const int64_t row = blockIdx.x;
+    const float* x = X + row * ldx;
+    for (int t = threadIdx.x; t < npow2; t += blockDim.x) {
+        float v = -INFINITY;
+        int i = 0x7fffffff;
+        if (t < cols) {
+            v = x[t];
+            if (clamp) v = (v > 0.f) ? v : 0.f;
+            i = t;
+        }
+        sv[t] = v;
+        si[t] = i;
+    }
+    __syncthreads();
+    for (int size = 2; size <= npow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < npow2 / 2; t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);  // "up" blocks end sorted in final order
+                const float va = sv[lo], vb = sv[hi];
+                const int ia = si[lo], ib = si[hi];
+                const bool wrong = up ? before(vb, ib, va, ia) : before(va, ia, vb, ib);
+                if (wrong) { sv[lo] = vb; sv[hi] = va; si[lo] = ib; si[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+        out_idx[row * k + t] = si[t];
+        if (out_val) out_val[row * k + t] = sv[t];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows_cols(const float* __restrict__ X, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t rows, int64_t cols, int64_t k) {
+    const int64_t total = rows * k;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / k;
+        out[t] = X[r * cols + idx[t]];
+    }
+}
+
+}  // namespace tmf
+
+using namespace tmf;
+
+extern "C" int tmf_predict_gemm_f32(const float* A, const float* B, float* C, int64_t m, int64_t n, int r,
+                                    int64_t lda, int64_t ldb, int64_t ldc, void* stream) {
+    if (m == 0 || n == 0) return TMF_OK;
+    TMF_REQUIRE(A && B && C && m > 0 && n > 0 && r > 0, "predict_gemm: bad arguments");
+    TMF_REQUIRE(lda >= r && ldb >= r && ldc >= n, "predict_gemm: leading dimension too small");
+    TMF_REQUIRE((lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0),
+                "predict_gemm: operands must be 16-byte aligned with ld %% 4 == 0");
+    const int64_t tm = (m + BM - 1) / BM, tn = (n + BN - 1) / BN;
+    TMF_REQUIRE(tm * tn < ((int64_t)1 << 31), "predict_gemm: too many tiles, chunk the users");
+    hipLaunchKernelGGL(k_predict_gemm, dim3((unsigned)(tm * tn)), dim3(256), 0, (hipStream_t)stream, A, B, C, m, n, r,
+                       lda, ldb, ldc, (int)tn);
+    return check_launch("tmf_predict_gemm_f32");
+}
+
+extern "C" int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, int k,
+                                   int clamp_negatives, int32_t* out_idx, float* out_val, void* stream) {
+    if (rows == 0) return TMF_OK;
+    TMF_REQUIRE(X && out_idx && rows > 0 && cols > 0 && ldx >= cols, "topk: bad arguments");
+    TMF_REQUIRE(k >= 1 && k <= cols, "topk: k=%d must be in [1, cols=%lld]", k, (long long)cols);
+    TMF_REQUIRE(cols < ((int64_t)1 << 31) && rows < ((int64_t)1 << 31), "topk: too large");
+    if (k <= 64) {
+        const size_t lds = (size_t)k * 64 * 8;
+        const bool vec = (ldx % 4 == 0) && ((uintptr_t)X % 16 == 0);
+        if (vec)
+            hipLaunchKernelGGL((k_topk_small<true>), dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream, X, cols,
+                               ldx, k, clamp_negatives, out_idx, out_val);
+        else
+            hipLaunchKernelGGL((k_topk_small<false>), dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream, X, cols,
+                               ldx, k, clamp_negatives, out_idx, out_val);
+        return check_launch("tmf_topk_stable_f32");
+    }
+    int npow2 = 1;
+    while (npow2 < cols) npow2 <<= 1;
+    const size_t lds = (size_t)npow2 * 8;
+    if (lds > 160 * 1024) {
+        set_error("topk: full ranking of %lld columns needs %zu bytes of LDS (max 163840); use k <= 64", (long long)cols, lds);
+        return TMF_E_UNSUPPORTED;
+    }
+    static size_t allowed = 64 * 1024;
+    if (lds > allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return TMF_E_LAUNCH;
+        }
+        allowed = lds;
+    }
+    const int threads = npow2 / 2 < 1024 ? (npow2 / 2 < 64 ? 64 : npow2 / 2) : 1024;
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)rows), dim3(threads), lds, (hipStream_t)stream, X, cols, ldx, k,
+                       clamp_negatives, npow2, out_idx, out_val);
+    return check_launch("tmf_topk_stable_f32");
+}
+
+extern "C" int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, float* out, int64_t rows,
+                                        int64_t cols, int64_t k, void* stream) {
+    if (rows * k == 0) return TMF_OK;
+    TMF_REQUIRE(X && idx && out && rows > 0 && cols > 0 && k > 0, "gather_rows_cols: bad arguments");
+    const int64_t want = (rows * k + 255) / 256;
+    hipLaunchKernelGGL(k_gather_rows_cols, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, X, idx, out, rows, cols, k);
+    return check_launch("tmf_gather_rows_cols_f32");
+}

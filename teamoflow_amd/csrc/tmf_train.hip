@@ -1,0 +1,293 @@
+// Row passes of one training epoch: MSE gather->dot->loss->gradient->Adam, the weighted
+// gather-sum used by the WMRB item side, the combine of multi-segment rows, the standalone
+// fresh-Adam row update and the deterministic loss sum.  See include/tmf.h for the contracts
+// and DESIGN.md for the bytes each kernel moves.
+#include "tmf_common.h"
+
+namespace tmf {
+
+constexpr int kWavesPerBlock = 4;   // 256 threads: four independent waves, no LDS, no barrier
+constexpr int kUnroll = 4;          // list entries a group keeps in flight
+
+struct SegView {
+    const int64_t* rowptr;
+    const int32_t* seg_row;
+    const int32_t* seg_chunk;
+    const int32_t* seg_slab;
+    int64_t nseg;
+    int32_t chunk;
+};
+
+// ---------------------------------------------------------------------------------------------
+// MSE pass.  One wave per segment; 64/G groups of G lanes each take every (64/G)-th entry of the
+// segment, kUnroll entries in flight per group.  p_k is reduced over the group with xor shuffles,
+// the gradient row is accumulated in registers and reduced over the groups once at the end.
+// ---------------------------------------------------------------------------------------------
+template <int G, int NV>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
+    SegView sv, const int32_t* __restrict__ other, const float* __restrict__ val,
+    const float* __restrict__ X_old, const float* __restrict__ Y_old, float* __restrict__ X_out,
+    float* __restrict__ slab, float* __restrict__ loss_part, int epi, tmf_adam adam) {
+    constexpr int NG = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (seg >= sv.nseg) return;
+    const int g = lane & (G - 1), grp = lane / G;
+    const int row = sv.seg_row[seg];
+    const int64_t rbeg = sv.rowptr[row], rend = sv.rowptr[row + 1];
+    const int64_t beg = rbeg + (int64_t)sv.seg_chunk[seg] * sv.chunk;
+    const int64_t end = (beg + sv.chunk < rend) ? beg + sv.chunk : rend;
+
+    Frag<NV> x, acc;
+    load_row<G, NV>(x, X_old, row, g);
+    zero<NV>(acc);
+    float lsum = 0.f;
+
+    for (int64_t k0 = beg + grp; k0 < end; k0 += (int64_t)NG * kUnroll) {
+        Frag<NV> y[kUnroll];
+        float a[kUnroll];
+        bool ok[kUnroll];
+#pragma unroll
+        for (int t = 0; t < kUnroll; ++t) {
+            const int64_t k = k0 + (int64_t)t * NG;
+            ok[t] = k < end;
+            if (ok[t]) {
+                const int j = other[k];
+                a[t] = val[k];
+                load_row<G, NV>(y[t], Y_old, j, g);
+            } else {
+                a[t] = 0.f;
+                zero<NV>(y[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kUnroll; ++t) {
+            const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
+            const float e = a[t] - p;          // padded slots: a = 0, y = 0 -> e = 0
+            lsum += e * e;
+            axpy<NV>(acc, -2.0f * e, y[t]);
+        }
+    }
+    across_groups_sum<G, NV>(acc);
+    if (loss_part != nullptr) {
+        // every lane of a group carries the same e*e: take lane 0 of each group
+        float l = (g == 0) ? lsum : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) l += __shfl_xor(l, off, 64);
+        if (lane == 0) loss_part[seg] = l;
+    }
+    if (grp == 0) {
+        const int slot = sv.seg_slab[seg];
+        if (slot < 0) row_epilogue<G, NV>(acc, X_old, X_out, row, g, epi, adam);
+        else store_row<G, NV>(acc, slab, slot, g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weighted gather-sum pass: g[row] = sum_e wbuf[ent_w[e]] * T[ent_row[e]].  The weights of the
+// next step are fetched while the rows of the current one are in flight, because a row is only
+// loaded when its weight is non-zero (two dependent reads otherwise).
+// ---------------------------------------------------------------------------------------------
+template <int G, int NV>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
+    SegView sv, const int32_t* __restrict__ ent_row, const int64_t* __restrict__ ent_w,
+    const float* __restrict__ wbuf, const float* __restrict__ T, const float* __restrict__ X_old,
+    float* __restrict__ X_out, float* __restrict__ slab, int epi, tmf_adam adam) {
+    constexpr int NG = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (seg >= sv.nseg) return;
+    const int g = lane & (G - 1), grp = lane / G;
+    const int row = sv.seg_row[seg];
+    const int64_t rbeg = sv.rowptr[row], rend = sv.rowptr[row + 1];
+    const int64_t beg = rbeg + (int64_t)sv.seg_chunk[seg] * sv.chunk;
+    const int64_t end = (beg + sv.chunk < rend) ? beg + sv.chunk : rend;
+
+    Frag<NV> acc;
+    zero<NV>(acc);
+
+    float w[kUnroll];
+    int src[kUnroll];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+        for (int t = 0; t < kUnroll; ++t) {
+            const int64_t k = k0 + (int64_t)t * NG;
+            if (k < end) {
+                src[t] = ent_row[k];
+                w[t] = wbuf[ent_w[k]];
+            } else {
+                src[t] = 0;
+                w[t] = 0.f;
+            }
+        }
+    };
+    int64_t k0 = beg + grp;
+    if (k0 < end) fetch(k0);
+    while (k0 < end) {
+        Frag<NV> y[kUnroll];
+        float wc[kUnroll];
+#pragma unroll
+        for (int t = 0; t < kUnroll; ++t) {
+            wc[t] = w[t];
+            if (wc[t] != 0.f) load_row<G, NV>(y[t], T, src[t], g);
+            else zero<NV>(y[t]);
+        }
+        k0 += (int64_t)NG * kUnroll;
+        if (k0 < end) fetch(k0);
+#pragma unroll
+        for (int t = 0; t < kUnroll; ++t) axpy<NV>(acc, wc[t], y[t]);
+    }
+    across_groups_sum<G, NV>(acc);
+    if (grp == 0) {
+        const int slot = sv.seg_slab[seg];
+        if (slot < 0) row_epilogue<G, NV>(acc, X_old, X_out, row, g, epi, adam);
+        else store_row<G, NV>(acc, slab, slot, g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rows cut into several segments: sum the slab slots in slot order (group t takes slots t, t+NG..
+// then the fixed butterfly over groups), then the epilogue.
+// ---------------------------------------------------------------------------------------------
+template <int G, int NV>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_combine_rows(
+    const int32_t* __restrict__ long_rows, const int64_t* __restrict__ slab_beg, int64_t n_long,
+    const float* __restrict__ slab, const float* __restrict__ X_old, float* __restrict__ X_out, int epi,
+    tmf_adam adam) {
+    constexpr int NG = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n_long) return;
+    const int g = lane & (G - 1), grp = lane / G;
+    const int row = long_rows[i];
+    const int64_t beg = slab_beg[i], end = slab_beg[i + 1];
+    Frag<NV> acc;
+    zero<NV>(acc);
+    for (int64_t s = beg + grp; s < end; s += NG) {
+        Frag<NV> y;
+        load_row<G, NV>(y, slab, s, g);
+        add<NV>(acc, y);
+    }
+    across_groups_sum<G, NV>(acc);
+    if (grp == 0) row_epilogue<G, NV>(acc, X_old, X_out, row, g, epi, adam);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 standalone: elementwise fresh-Adam over a [n_rows, ld] table (float4 per lane, grid-stride).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam_rows(float4* __restrict__ W, const float4* __restrict__ Gr,
+                                                   int64_t n4, tmf_adam adam) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 w = W[i];
+        const float4 g = Gr[i];
+        w.x = adam_fresh(w.x, g.x, adam);
+        w.y = adam_fresh(w.y, g.y, adam);
+        w.z = adam_fresh(w.z, g.z, adam);
+        w.w = adam_fresh(w.w, g.w, adam);
+        W[i] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic sum: one 1024-thread block, strided fp64 partials, fixed LDS tree.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sum_f32(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)x[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+static inline SegView view(const tmf_segments* s) {
+    return SegView{s->rowptr, s->seg_row, s->seg_chunk, s->seg_slab, s->nseg, s->chunk};
+}
+
+static int check_segments(const tmf_segments* s) {
+    TMF_REQUIRE(s != nullptr, "segments is null");
+    TMF_REQUIRE(s->nseg >= 0 && s->chunk > 0, "segments: nseg=%lld chunk=%d", (long long)s->nseg, s->chunk);
+    TMF_REQUIRE(s->nseg == 0 || (s->rowptr && s->seg_row && s->seg_chunk && s->seg_slab), "segments: null array");
+    TMF_REQUIRE(s->nseg < ((int64_t)1 << 31) * kWavesPerBlock, "segments: too many segments");
+    return TMF_OK;
+}
+
+}  // namespace tmf
+
+using namespace tmf;
+
+extern "C" int tmf_mse_pass_f32(const tmf_segments* seg, const int32_t* other, const float* val,
+                                const float* X_old, const float* Y_old, float* X_out, float* slab,
+                                float* loss_part, int n_components, int epi, tmf_adam adam, void* stream) {
+    if (int rc = check_segments(seg)) return rc;
+    if (seg->nseg == 0) return TMF_OK;
+    TMF_REQUIRE(X_old && Y_old && X_out, "mse_pass: null table");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "mse_pass: bad epilogue %d", epi);
+    const RowGeom geom = row_geom(n_components);
+    const SegView sv = view(seg);
+    const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
+#define CALL(G_, NV_)                                                                                    \
+    hipLaunchKernelGGL((k_mse_pass<G_, NV_>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       sv, other, val, X_old, Y_old, X_out, slab, loss_part, epi, adam)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_mse_pass_f32");
+}
+
+extern "C" int tmf_wsum_pass_f32(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w,
+                                 const float* wbuf, const float* T, const float* X_old, float* X_out,
+                                 float* slab, int n_components, int epi, tmf_adam adam, void* stream) {
+    if (int rc = check_segments(seg)) return rc;
+    if (seg->nseg == 0) return TMF_OK;
+    TMF_REQUIRE(T && X_out && (epi == TMF_EPI_GRAD || X_old), "wsum_pass: null table");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wsum_pass: bad epilogue %d", epi);
+    const RowGeom geom = row_geom(n_components);
+    const SegView sv = view(seg);
+    const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
+#define CALL(G_, NV_)                                                                                     \
+    hipLaunchKernelGGL((k_wsum_pass<G_, NV_>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       sv, ent_row, ent_w, wbuf, T, X_old, X_out, slab, epi, adam)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_wsum_pass_f32");
+}
+
+extern "C" int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
+                                    const float* slab, const float* X_old, float* X_out, int n_components,
+                                    int epi, tmf_adam adam, void* stream) {
+    if (n_long == 0) return TMF_OK;
+    TMF_REQUIRE(n_long > 0 && long_rows && slab_beg && slab && X_out, "combine_rows: bad arguments");
+    TMF_REQUIRE(epi == TMF_EPI_GRAD || X_old, "combine_rows: X_old is null");
+    const RowGeom geom = row_geom(n_components);
+    const unsigned blocks = (unsigned)((n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+#define CALL(G_, NV_)                                                                                        \
+    hipLaunchKernelGGL((k_combine_rows<G_, NV_>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       long_rows, slab_beg, n_long, slab, X_old, X_out, epi, adam)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_combine_rows_f32");
+}
+
+extern "C" int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,
+                                       tmf_adam adam, void* stream) {
+    if (n_rows == 0) return TMF_OK;
+    const RowGeom geom = row_geom(n_components);
+    TMF_REQUIRE(geom.ld > 0, "adam_fresh_rows: unsupported n_components %d", n_components);
+    TMF_REQUIRE(W && G && n_rows > 0, "adam_fresh_rows: bad arguments");
+    const int64_t n4 = n_rows * geom.ld / 4;
+    const int64_t want = (n4 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_adam_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(W), reinterpret_cast<const float4*>(G), n4, adam);
+    return check_launch("tmf_adam_fresh_rows_f32");
+}
+
+extern "C" int tmf_sum_f32(const float* x, int64_t n, double* out, void* stream) {
+    TMF_REQUIRE(out && n >= 0 && (n == 0 || x), "sum: bad arguments");
+    hipLaunchKernelGGL(k_sum_f32, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+    return check_launch("tmf_sum_f32");
+}

@@ -1,0 +1,269 @@
+// K4+K5: user side of one WMRB epoch.  One 256-thread workgroup per user:
+//   phase 1  sp[s] = <U[u], V[R[u,s]]> for the S static negatives      -> LDS
+//   phase 2  per chunk of the user's interactions (<= kPosChunk):
+//              2a p_k for positives, c1_k = 1 - p_k                      -> LDS
+//              2b M_k = c*sum_s max(c1_k + sp[s], 0), cnt_k, w_k, delta_k, log(1+M_k)
+//              2c D[s] += sum_k [c1_k + sp[s] >= 0] w_k                  (thread per sample)
+//              2d gU += sum_k delta_k V[j_k]
+//   phase 3  gU += sum_s D[s] V[R[u,s]], D -> global, gU -> epilogue (fresh Adam or raw gradient)
+// The [P, S] hinge tensor of loss_graphs.py:80-84 is never materialised.
+#include <math.h>
+
+#include "tmf_common.h"
+
+namespace tmf {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kPosChunk = 512;
+constexpr int kUnrollW = 4;
+
+__host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
+
+template <int G, int NV>
+__global__ __launch_bounds__(kThreads) void k_wmrb_user(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const int32_t* __restrict__ R, int S, float c, const float* __restrict__ U_old,
+    const float* __restrict__ V_old, float* __restrict__ U_out, float* __restrict__ delta,
+    float* __restrict__ Dg, float* __restrict__ loss_part, float* __restrict__ pos_part, int epi,
+    tmf_adam adam) {
+    constexpr int NG = 64 / G;          // groups per wave
+    constexpr int NGB = NG * kWaves;    // groups per block
+    constexpr int LD = 4 * G * NV;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int S4 = round4(S);
+    float* sp = reinterpret_cast<float*>(smem_raw);   // [S4]   sampled scores (tail = -inf)
+    float* Dl = sp + S4;                              // [S4]   D[u, :]
+    float* c1 = Dl + S4;                              // [kPosChunk] 1 - p_k, -inf for non-positives
+    float* wl = c1 + kPosChunk;                       // [kPosChunk] w_k
+    float* dl = wl + kPosChunk;                       // [kPosChunk] delta_k
+    float* red = dl + kPosChunk;                      // [kWaves][LD] + 2*kWaves
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane & (G - 1), grp = lane / G, gid = wave * NG + grp;
+    const int64_t u = blockIdx.x;
+    const int64_t rb = rowptr[u], re = rowptr[u + 1];
+    const int32_t* Ru = R + u * (int64_t)S;
+
+    // phase 0: any positive at all?
+    int mine = 0;
+    for (int64_t k = rb + tid; k < re; k += kThreads) mine |= (val[k] > 0.f);
+    const int anypos = __syncthreads_or(mine);
+
+    Frag<NV> acc;
+    zero<NV>(acc);
+    float lsum = 0.f, npos = 0.f;
+
+    if (!anypos) {
+        for (int64_t k = rb + tid; k < re; k += kThreads) delta[k] = 0.f;
+        for (int s = tid; s < S; s += kThreads) Dg[u * (int64_t)S + s] = 0.f;
+    } else {
+        Frag<NV> x;
+        load_row<G, NV>(x, U_old, u, g);
+        // ---- phase 1 ----
+        for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
+            Frag<NV> y[kUnrollW];
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) {
+                const int s = s0 + t * NGB;
+                if (s < S) load_row<G, NV>(y[t], V_old, Ru[s], g);
+                else zero<NV>(y[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) {
+                const int s = s0 + t * NGB;
+                const float d = group_allsum<G>(dot_partial<NV>(x, y[t]));
+                if (g == 0 && s < S) sp[s] = d;
+            }
+        }
+        for (int s = tid; s < S4; s += kThreads) {
+            Dl[s] = 0.f;
+            if (s >= S) sp[s] = -INFINITY;
+        }
+        __syncthreads();
+
+        // ---- phase 2 ----
+        for (int64_t cb = rb; cb < re; cb += kPosChunk) {
+            const int len = (int)((re - cb < kPosChunk) ? (re - cb) : kPosChunk);
+            const int len4 = round4(len);
+            // 2a
+            for (int k0 = gid; k0 < len; k0 += NGB * kUnrollW) {
+                Frag<NV> y[kUnrollW];
+                bool pos[kUnrollW];
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) {
+                    const int kk = k0 + t * NGB;
+                    pos[t] = (kk < len) && (val[cb + kk] > 0.f);
+                    if (pos[t]) load_row<G, NV>(y[t], V_old, col[cb + kk], g);
+                    else zero<NV>(y[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) {
+                    const int kk = k0 + t * NGB;
+                    const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
+                    if (g == 0 && kk < len) c1[kk] = pos[t] ? (1.0f - p) : -INFINITY;
+                }
+            }
+            for (int kk = len + tid; kk < len4; kk += kThreads) {
+                c1[kk] = -INFINITY;
+                wl[kk] = 0.f;
+            }
+            __syncthreads();
+            // 2b: one thread per interaction of the chunk
+            for (int kk = tid; kk < len; kk += kThreads) {
+                const float c1v = c1[kk];
+                float w = 0.f, d = 0.f;
+                if (c1v != -INFINITY) {
+                    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+                    int cnt = 0;
+                    const float4* sp4 = reinterpret_cast<const float4*>(sp);
+                    for (int s = 0; s < S4 / 4; ++s) {
+                        const float4 q = sp4[s];
+                        const float x0 = c1v + q.x, x1 = c1v + q.y, x2 = c1v + q.z, x3 = c1v + q.w;
+                        m0 += fmaxf(x0, 0.f);
+                        m1 += fmaxf(x1, 0.f);
+                        m2 += fmaxf(x2, 0.f);
+                        m3 += fmaxf(x3, 0.f);
+                        cnt += (x0 >= 0.f) + (x1 >= 0.f) + (x2 >= 0.f) + (x3 >= 0.f);
+                    }
+                    const float M = c * ((m0 + m1) + (m2 + m3));
+                    lsum += logf(1.0f + M);
+                    npos += 1.f;
+                    w = c * __frcp_rn(1.0f + M);
+                    d = -(w * (float)cnt);
+                }
+                wl[kk] = w;
+                dl[kk] = d;
+                delta[cb + kk] = d;
+            }
+            __syncthreads();
+            // 2c: one thread per sample
+            for (int s = tid; s < S; s += kThreads) {
+                const float sps = sp[s];
+                float dsum = 0.f;
+                const float4* c4 = reinterpret_cast<const float4*>(c1);
+                const float4* w4 = reinterpret_cast<const float4*>(wl);
+                for (int q = 0; q < len4 / 4; ++q) {
+                    const float4 cc = c4[q], ww = w4[q];
+                    dsum += (cc.x + sps >= 0.f) ? ww.x : 0.f;
+                    dsum += (cc.y + sps >= 0.f) ? ww.y : 0.f;
+                    dsum += (cc.z + sps >= 0.f) ? ww.z : 0.f;
+                    dsum += (cc.w + sps >= 0.f) ? ww.w : 0.f;
+                }
+                Dl[s] += dsum;
+            }
+            // 2d
+            for (int k0 = gid; k0 < len; k0 += NGB * kUnrollW) {
+                Frag<NV> y[kUnrollW];
+                float d[kUnrollW];
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) {
+                    const int kk = k0 + t * NGB;
+                    d[t] = (kk < len) ? dl[kk] : 0.f;
+                    if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, col[cb + kk], g);
+                    else zero<NV>(y[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) axpy<NV>(acc, d[t], y[t]);
+            }
+            __syncthreads();
+        }
+        // ---- phase 3 ----
+        for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
+            Frag<NV> y[kUnrollW];
+            float d[kUnrollW];
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) {
+                const int s = s0 + t * NGB;
+                d[t] = (s < S) ? Dl[s] : 0.f;
+                if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, Ru[s], g);
+                else zero<NV>(y[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) axpy<NV>(acc, d[t], y[t]);
+        }
+        for (int s = tid; s < S; s += kThreads) Dg[u * (int64_t)S + s] = Dl[s];
+    }
+
+    // ---- block reduction of gU (groups of a wave, then the four waves in order) and of the loss ----
+    across_groups_sum<G, NV>(acc);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lsum += __shfl_xor(lsum, off, 64);
+        npos += __shfl_xor(npos, off, 64);
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(red + wave * LD)[g + G * v] = acc.v[v];
+    }
+    if (lane == 0) {
+        red[kWaves * LD + wave] = lsum;
+        red[kWaves * LD + kWaves + wave] = npos;
+    }
+    __syncthreads();
+    if (wave == 0 && grp == 0) {
+        Frag<NV> tot;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) tot.v[v] = reinterpret_cast<const float4*>(red)[g + G * v];
+        for (int w = 1; w < kWaves; ++w) {
+            Frag<NV> part;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) part.v[v] = reinterpret_cast<const float4*>(red + w * LD)[g + G * v];
+            add<NV>(tot, part);
+        }
+        row_epilogue<G, NV>(tot, U_old, U_out, u, g, epi, adam);
+    }
+    if (tid == 0) {
+        const float* t = red + kWaves * LD;
+        if (loss_part) loss_part[u] = (t[0] + t[1]) + (t[2] + t[3]);
+        if (pos_part) pos_part[u] = (t[4] + t[5]) + (t[6] + t[7]);
+    }
+}
+
+template <int G, int NV>
+static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
+                            int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
+                            float* U_out, float* delta, float* D, float* loss_part, float* pos_part, int epi,
+                            tmf_adam adam, hipStream_t stream) {
+    const size_t lds = sizeof(float) * ((size_t)2 * round4(S) + 3 * kPosChunk + (size_t)kWaves * 4 * G * NV + 2 * kWaves);
+    if (lds > 160 * 1024) {
+        set_error("wmrb_user_pass: n_samples=%d needs %zu bytes of LDS (max 163840)", S, lds);
+        return TMF_E_UNSUPPORTED;
+    }
+    static size_t allowed = 64 * 1024;  // per template instance
+    if (lds > allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return TMF_E_LAUNCH;
+        }
+        allowed = lds;
+    }
+    hipLaunchKernelGGL((k_wmrb_user<G, NV>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col, val,
+                       R, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
+    return check_launch("tmf_wmrb_user_pass_f32");
+}
+
+}  // namespace tmf
+
+using namespace tmf;
+
+extern "C" int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                                      const int32_t* R, int32_t n_users, int32_t S, float c,
+                                      const float* U_old, const float* V_old, float* U_out, float* delta,
+                                      float* D, float* loss_part, float* pos_part, int n_components, int epi,
+                                      tmf_adam adam, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(n_users > 0 && S > 0, "wmrb_user_pass: n_users=%d S=%d", n_users, S);
+    TMF_REQUIRE(rowptr && R && U_old && V_old && U_out && D, "wmrb_user_pass: null pointer");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_user_pass: bad epilogue %d", epi);
+    const RowGeom geom = row_geom(n_components);
+#define CALL(G_, NV_)                                                                                           \
+    return launch_wmrb_user<G_, NV_>(rowptr, col, val, R, n_users, S, c, U_old, V_old, U_out, delta, D, loss_part, \
+                                     pos_part, epi, adam, (hipStream_t)stream)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return TMF_OK;
+}

@@ -1,0 +1,262 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden fixtures.  Tolerances: indices / top-k bit-exact; loss, gradients and predictions
+1e-5 relative (norm-wise, fp32); factor tables per conftest.weights_close."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err, weights_close
+
+pytestmark = pytest.mark.gpu
+
+spec = importlib.util.spec_from_file_location('make_golden', os.path.join(GOLDEN, 'make_golden.py'))
+MG = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(MG)
+
+
+@pytest.fixture(scope='module')
+def tm():
+    from teamoflow_amd import _engine, _lib, _ops
+    from teamoflow_amd.mf import initializer_graphs, loss_graphs, matrix_factorization, sparse, utils
+    _lib.get()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.engine, ns.lib, ns.ops = _engine, _lib, _ops
+    ns.MF = matrix_factorization.MatrixFactorization
+    ns.Fixed = initializer_graphs.FixedInitializer
+    ns.WMRB = loss_graphs.WMRBLoss
+    ns.Sparse = sparse.SparseInteractions
+    ns.eye = sparse.eye
+    ns.utils = utils
+    return ns
+
+
+def fit_model(tm, U0, V0, idx, val, shape, epochs, lr, loss='mse', R=None, n_items=None, n_samples=None):
+    m, n = shape
+    kw = dict(user_weight_graph=tm.Fixed(U0), item_weight_graph=tm.Fixed(V0))
+    if loss == 'wmrb':
+        kw.update(loss_graph=tm.WMRB(), n_users=m, n_items=n_items, n_samples=n_samples)
+    model = tm.MF(U0.shape[1], **kw)
+    if loss == 'wmrb':
+        model.random_ind = torch.as_tensor(R)
+    model.verbose = False
+    model.fit(epochs, tm.eye(m), tm.eye(n), tm.Sparse(idx, val, shape), lr=lr)
+    return model
+
+
+def test_gather_matrix_indices_known_answer(tm, golden):
+    g = golden('gather_known_answer')
+    out = tm.utils.gather_matrix_indices(torch.tensor(g['input']), torch.tensor(g['index']))
+    assert np.array_equal(out.cpu().numpy(), g['expected'])
+
+
+def test_c1_mse_trajectory_and_ranking(tm, golden):
+    g = golden('c1_mse')
+    lr = float(g['lr'])
+    model = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 25, lr)
+    assert rel_err(model.loss_history_, g['loss'][:25]) < 1e-5
+    ok, err, tol = weights_close(model.user_embedding.cpu().numpy(), g['U_25'], lr, frac_lr=0.25)
+    assert ok, (err, tol)
+    one = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 1, lr)
+    for got, want in ((one.user_embedding, g['U_1']), (one.item_embedding, g['V_1'])):
+        ok, err, tol = weights_close(got.cpu().numpy(), want, lr)
+        assert ok, (err, tol)
+    # teacher-forced single steps from the oracle's own state late in training
+    two = fit_model(tm, g['U_25'], g['V_25'], g['indices'], g['values'], g['A'].shape, 1, lr)
+    from oracle import sparse_ref as S
+    Uw, Vw, lw, _ = S.mse_epoch(g['U_25'], g['V_25'], g['indices'], g['values'], lr)
+    assert abs(two.loss_history_[0] - lw) / lw < 1e-5
+    assert weights_close(two.user_embedding.cpu().numpy(), Uw, lr)[0]
+    assert weights_close(two.item_embedding.cpu().numpy(), Vw, lr)[0]
+
+
+def test_c1_full_run_predict_topk_recall(tm, golden):
+    g = golden('c1_mse')
+    m, n = g['A'].shape
+    model = tm.MF(5)
+    model.user_embedding = torch.tensor(g['U_450']).cuda()
+    model.item_embedding = torch.tensor(g['V_450']).cuda()
+    pred = model.predict().cpu().numpy()
+    assert rel_err(pred, g['predictions']) < 1e-5
+    assert np.array_equal(model.retrieve_user_recs(k=10), g['top10'])
+    assert model.retrieve_user_recs(k=10).dtype == np.int32
+    full = model.retrieve_user_recs()
+    assert full.shape == (m, n) and np.array_equal(full[:, :10], g['top10'])
+    assert np.array_equal(model.retrieve_user_recs(user=3, k=7), g['top10'][3, :7])
+    A = torch.tensor(g['A'])
+    assert np.array_equal(model.recall_at_k(A).cpu().numpy(), g['recall10'])
+    assert np.array_equal(model.recall_at_k(A, preserve_rows=True).cpu().numpy(), g['recall10_rows'])
+    assert np.array_equal(model.precision_at_k(A).cpu().numpy(), g['precision10'])
+    sp = tm.Sparse(g['indices'], g['values'], (m, n))
+    assert np.array_equal(model.recall_at_k(sp).cpu().numpy(), g['recall10'])
+    allp, unobs = model.predict(A)
+    assert unobs.shape[0] == int((g['A'] == 0).sum())
+
+
+def test_c2_mse(tm, golden):
+    g = golden('c2_mse')
+    idx, val, A, U0, V0 = MG.c2_inputs()
+    lr = float(g['lr'])
+    model = fit_model(tm, U0, V0, idx, val, A.shape, 100, lr)
+    assert rel_err(model.loss_history_[:10], g['loss'][:10]) < 1e-5
+    assert rel_err(model.loss_history_, g['loss']) < 1e-4  # 100 near-sign Adam steps amplify rounding
+    one = fit_model(tm, U0, V0, idx, val, A.shape, 1, lr)
+    assert weights_close(one.user_embedding.cpu().numpy(), g['U_1'], lr)[0]
+    assert weights_close(one.item_embedding.cpu().numpy(), g['V_1'], lr)[0]
+    rec = float(model.recall_at_k(torch.tensor(A)).mean())
+    assert abs(rec - float(g['recall10_mean'])) <= 1e-3
+
+
+@pytest.mark.parametrize('name', ['wmrb_small', 'wmrb_mixed'])
+def test_wmrb_fixtures(tm, golden, name):
+    g = golden(name)
+    lr, n_items, n_samples = float(g['lr']), int(g['n_items']), int(g['n_samples'])
+    E = len(g['loss'])
+    model = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, E, lr, 'wmrb', g['R'], n_items,
+                      n_samples)
+    assert rel_err(model.loss_history_[:3], g['loss'][:3]) < 1e-5
+    assert rel_err(model.loss_history_, g['loss']) < 2e-3
+    one = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 1, lr, 'wmrb', g['R'], n_items,
+                    n_samples)
+    for got, want in ((one.user_embedding, g['U_1']), (one.item_embedding, g['V_1'])):
+        ok, err, tol = weights_close(got.cpu().numpy(), want, lr)
+        assert ok, (name, err, tol)
+    if name == 'wmrb_small':
+        st = one._state
+        assert rel_err(st.wplan.D.cpu().numpy(), g['D_first']) < 1e-5
+        pos = g['values'] > 0
+        assert rel_err(st.wplan.delta.cpu().numpy()[pos], g['delta_first']) < 1e-5
+
+
+def test_c3r_wmrb(tm, golden):
+    g = golden('c3r_wmrb')
+    idx, val, A, R, U0, V0 = MG.c3r_inputs()
+    m, n = A.shape
+    lr = float(g['lr'])
+    model = fit_model(tm, U0, V0, idx, val, A.shape, 3, lr, 'wmrb', R, n, n // 2)
+    assert rel_err(model.loss_history_, g['loss'][:3]) < 1e-5
+    one = fit_model(tm, U0, V0, idx, val, A.shape, 1, lr, 'wmrb', R, n, n // 2)
+    assert weights_close(one.user_embedding.cpu().numpy(), g['U_1'], lr)[0]
+    assert weights_close(one.item_embedding.cpu().numpy(), g['V_1'], lr)[0]
+
+
+@pytest.mark.parametrize('r', [1, 3, 4, 7, 16, 33, 64, 100, 128, 200, 256, 300, 512])
+def test_every_rank_geometry_mse_and_wmrb(tm, r):
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(r)
+    m, n, S_ = 37, 29, 11
+    A = (rng.random((m, n)) < 0.2) * rng.integers(-2, 6, (m, n))
+    idx = np.argwhere(A != 0)
+    val = A[A != 0].astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
+    lr = 0.01
+    mse = fit_model(tm, U0, V0, idx, val, (m, n), 1, lr)
+    Uw, Vw, lw, _ = S.mse_epoch(U0, V0, idx, val, lr)
+    assert abs(mse.loss_history_[0] - lw) / lw < 1e-5
+    assert weights_close(mse.user_embedding.cpu().numpy(), Uw, lr)[0]
+    assert weights_close(mse.item_embedding.cpu().numpy(), Vw, lr)[0]
+    w = fit_model(tm, U0, V0, idx, val, (m, n), 1, lr, 'wmrb', R, n, S_)
+    Uw, Vw, lw, t = S.wmrb_epoch(U0, V0, idx, val, R, n, S_, lr)
+    assert abs(w.loss_history_[0] - lw) / lw < 1e-5
+    assert weights_close(w.user_embedding.cpu().numpy(), Uw, lr)[0]
+    assert weights_close(w.item_embedding.cpu().numpy(), Vw, lr)[0]
+    assert rel_err(w._state.wplan.D.cpu().numpy(), t['D']) < 1e-5
+
+
+def test_heavy_rows_are_segmented_and_combined(tm):
+    """Rows longer than the segment length go through the slab + combine path."""
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(7)
+    m, n, r = 6, 5000, 32
+    A = np.zeros((m, n), np.float32)
+    A[0, :] = rng.integers(1, 6, n)           # one user with 5000 interactions (5 segments)
+    A[1, :1024] = 3                            # exactly one full segment
+    A[2, :1025] = 2                            # one entry into the second segment
+    A[4, ::7] = rng.integers(1, 6, len(A[4, ::7]))
+    idx = np.argwhere(A != 0)
+    val = A[A != 0]
+    U0 = (rng.standard_normal((m, r)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.1).astype(np.float32)
+    model = fit_model(tm, U0, V0, idx, val, (m, n), 1, 0.01)
+    assert model._state.plan.seg_u.n_long == 2 and model._state.plan.seg_u.n_slab == 5 + 2
+    Uw, Vw, lw, _ = S.mse_epoch(U0, V0, idx, val, 0.01)
+    assert abs(model.loss_history_[0] - lw) / lw < 1e-5
+    assert weights_close(model.user_embedding.cpu().numpy(), Uw, 0.01)[0]
+    assert weights_close(model.item_embedding.cpu().numpy(), Vw, 0.01)[0]
+    assert np.array_equal(model.user_embedding.cpu().numpy()[3], U0[3])  # user without interactions: untouched
+
+
+def test_unsorted_and_duplicate_interactions(tm):
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(11)
+    m, n, r = 20, 30, 8
+    idx = np.stack([rng.integers(0, m, 200), rng.integers(0, n, 200)], axis=1)  # unsorted, with duplicates
+    val = rng.integers(1, 6, 200).astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.2).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.2).astype(np.float32)
+    model = fit_model(tm, U0, V0, idx, val, (m, n), 1, 0.01)
+    Uw, Vw, lw, _ = S.mse_epoch(U0, V0, idx, val, 0.01)
+    assert abs(model.loss_history_[0] - lw) / lw < 1e-5
+    assert weights_close(model.user_embedding.cpu().numpy(), Uw, 0.01)[0]
+    assert weights_close(model.item_embedding.cpu().numpy(), Vw, 0.01)[0]
+
+
+def test_empty_interactions_leave_tables_unchanged(tm):
+    U0 = np.random.default_rng(0).standard_normal((5, 4)).astype(np.float32)
+    V0 = np.random.default_rng(1).standard_normal((6, 4)).astype(np.float32)
+    model = fit_model(tm, U0, V0, np.zeros((0, 2), np.int64), np.zeros(0, np.float32), (5, 6), 2, 0.01)
+    assert np.array_equal(model.user_embedding.cpu().numpy(), U0)
+    assert np.array_equal(model.item_embedding.cpu().numpy(), V0)
+    assert all(np.isnan(x) for x in model.loss_history_)
+
+
+def test_topk_tie_rule_and_clamp(tm):
+    x = torch.tensor([[0., 1, 1, 0, 1], [-1., -2, -3, -4, -5]])
+    assert tm.ops.topk_stable(x, 3).cpu().tolist() == [[1, 2, 4], [0, 1, 2]]
+    assert tm.ops.topk_stable(x, 3, clamp_negatives=True).cpu().tolist() == [[1, 2, 4], [0, 1, 2]]
+    z = torch.zeros(3, 1000)
+    assert tm.ops.topk_stable(z, 10).cpu().tolist() == [list(range(10))] * 3
+    rng = np.random.default_rng(5)
+    for cols in (1, 7, 64, 257, 1000, 4099):
+        y = torch.tensor(rng.integers(-3, 4, (17, cols)).astype(np.float32))  # many ties
+        for k in sorted({1, min(10, cols), min(64, cols), min(100, cols), cols}):
+            if k > 64 and cols > 16384:
+                continue
+            want = torch.sort(y, dim=1, descending=True, stable=True)[1][:, :k]
+            got = tm.ops.topk_stable(y, k).cpu()
+            assert torch.equal(got.to(torch.int64), want), (cols, k)
+            wc = torch.sort(torch.clamp(y, min=0), dim=1, descending=True, stable=True)[1][:, :k]
+            assert torch.equal(tm.ops.topk_stable(y, k, clamp_negatives=True).cpu().to(torch.int64), wc), (cols, k)
+    with pytest.raises(ValueError):
+        tm.ops.topk_stable(x, 6)
+
+
+def test_predict_gemm_shapes(tm):
+    rng = np.random.default_rng(3)
+    for m, n, r in [(1, 1, 1), (100, 50, 5), (129, 257, 32), (300, 1000, 128), (64, 64, 7)]:
+        U = torch.tensor(rng.standard_normal((m, r)).astype(np.float32))
+        V = torch.tensor(rng.standard_normal((n, r)).astype(np.float32))
+        got = tm.ops.predict_gemm(U, V).cpu().numpy()
+        want = (U.double() @ V.double().T).numpy()
+        assert rel_err(got, want) < 1e-5, (m, n, r)
+
+
+def test_wmrb_without_sample_table_raises(tm):
+    model = tm.MF(3, loss_graph=tm.WMRB(), n_users=5, n_items=6)
+    with pytest.raises(AttributeError):
+        model.fit(1, tm.eye(5), tm.eye(6), tm.Sparse(np.array([[0, 1]]), np.array([1.0]), (5, 6)))
+
+
+def test_runs_are_bit_reproducible(tm, golden):
+    g = golden('wmrb_small')
+    a = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 5, 0.1, 'wmrb', g['R'], 100, 50)
+    b = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 5, 0.1, 'wmrb', g['R'], 100, 50)
+    assert torch.equal(a.user_embedding, b.user_embedding) and torch.equal(a.item_embedding, b.item_embedding)
+    assert a.loss_history_ == b.loss_history_

@@ -1,0 +1,139 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/tmf.h declares, the host-side
+index builders agree with a NumPy restatement, the engine refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from teamoflow_amd import _lib
+    import __graft_entry__ as ge
+    ge.build()
+    lib = _lib.load_library()
+    header = open(os.path.join(ROOT, 'include', 'tmf.h')).read()
+    declared = set(re.findall(r'\b(tmf_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations found'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.tmf_version() == 100
+
+
+def test_padded_ld_and_adam_constants_match_host_mirror():
+    from teamoflow_amd import _lib
+    from oracle.dense_ref import adam_fresh_constants
+    lib = _lib.load_library()
+    for r in list(range(1, 70)) + [100, 128, 129, 255, 256, 257, 512, 513, 768, 1024]:
+        assert lib.tmf_padded_ld(r) == _lib.padded_ld(r) >= r
+        assert _lib.padded_ld(r) % 4 == 0
+    assert lib.tmf_padded_ld(0) == 0 and lib.tmf_padded_ld(1025) == 0
+    for lr in (1e-2, 1e-3, 0.1, 0.05):
+        a = lib.tmf_adam_fresh(lr)
+        alpha, omb1, omb2, eps = adam_fresh_constants(lr)
+        assert (np.float32(a.alpha), np.float32(a.one_minus_b1), np.float32(a.one_minus_b2), np.float32(a.eps)) == \
+            (alpha, omb1, omb2, eps)
+
+
+def test_engine_refuses_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from teamoflow_amd import _lib
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    from teamoflow_amd.mf.sparse import SparseInteractions, eye
+    with pytest.raises(_lib.EngineUnavailable):
+        _lib.get()
+    model = MatrixFactorization(3)
+    with pytest.raises(_lib.EngineUnavailable):
+        model.fit(1, eye(4), eye(5), SparseInteractions(np.array([[0, 1]]), np.array([1.0]), (4, 5)))
+
+
+def test_segment_table_and_plans_against_numpy():
+    from teamoflow_amd._engine import InteractionPlan, SegmentTable, WmrbPlan
+    rng = np.random.default_rng(0)
+    m, n, S, chunk = 13, 9, 4, 5
+    idx = np.stack([rng.integers(0, m, 120), rng.integers(0, n, 120)], axis=1)
+    val = rng.integers(-1, 4, 120).astype(np.float32)
+    plan = InteractionPlan(torch.tensor(idx), torch.tensor(val), m, n, chunk=chunk)
+    order = np.argsort(idx[:, 0], kind='stable')
+    u, j, v = idx[order, 0], idx[order, 1], val[order]
+    assert np.array_equal(plan.col_u.numpy(), j) and np.array_equal(plan.val_u.numpy(), v)
+    assert np.array_equal(plan.rowptr_u.numpy(), np.concatenate([[0], np.cumsum(np.bincount(u, minlength=m))]))
+    oc = np.argsort(j, kind='stable')
+    assert np.array_equal(plan.row_i.numpy(), u[oc]) and np.array_equal(plan.val_i.numpy(), v[oc])
+    # segments: every entry covered exactly once, slab slots consecutive per long row
+    seg = plan.seg_u
+    covered = np.zeros(len(v), int)
+    rp = seg.rowptr.numpy()
+    for s in range(seg.nseg):
+        row, ch, slot = int(seg.seg_row[s]), int(seg.seg_chunk[s]), int(seg.seg_slab[s])
+        beg = rp[row] + ch * chunk
+        end = min(beg + chunk, rp[row + 1])
+        covered[beg:end] += 1
+        nch = max(1, -(-(rp[row + 1] - rp[row]) // chunk))
+        assert (slot == -1) == (nch == 1)
+    assert (covered == 1).all()
+    lb = seg.long_slab_beg.numpy()
+    for i, row in enumerate(seg.long_rows.numpy()):
+        slots = seg.seg_slab.numpy()[seg.seg_row.numpy() == row]
+        assert list(slots) == list(range(lb[i], lb[i + 1]))
+    assert seg.n_slab == lb[-1]
+    # WMRB entry lists: per item, positives (ascending user) then (user, slot) pairs
+    R = np.stack([rng.choice(n, S, replace=False) for _ in range(m)]).astype(np.int32)
+    w = WmrbPlan(plan, torch.tensor(R), chunk=chunk)
+    rpe = w.rowptr_e.numpy()
+    for item in range(n):
+        rows = w.ent_row.numpy()[rpe[item]:rpe[item + 1]]
+        ws = w.ent_w.numpy()[rpe[item]:rpe[item + 1]]
+        pos_k = np.nonzero((j == item) & (v > 0))[0]
+        us, ss = np.nonzero(R == item)
+        assert list(ws) == list(pos_k) + list(len(v) + us * S + ss)
+        assert list(rows) == list(u[pos_k]) + list(us)
+    assert w.delta.numel() == len(v) and tuple(w.D.shape) == (m, S)
+
+
+def test_reference_style_imports_and_surface():
+    import teamoflow
+    from teamoflow.mf import matrix_factorization, loss_graphs, embedding_graphs, initializer_graphs, predict_graphs, utils  # noqa
+    from teamoflow.mf.matrix_factorization import MatrixFactorization
+    import inspect
+    sig = inspect.signature(MatrixFactorization.__init__)
+    assert list(sig.parameters)[1:] == ['n_components', 'user_repr_graph', 'item_repr_graph', 'loss_graph',
+                                        'user_weight_graph', 'item_weight_graph', 'n_users', 'n_items', 'n_samples',
+                                        'generate_sample']
+    assert list(inspect.signature(MatrixFactorization.fit).parameters)[1:] == ['epochs', 'user_features',
+                                                                                 'item_features', 'tf_interactions', 'lr']
+    for name in ('predict', 'predict_ranks', 'recall_at_k', 'precision_at_k', 'f1_at_k', 'dcg_at_k', 'idcg_at_k',
+                 'ndcg_at_k', 'retrieve_user_recs', 'save_model', 'from_saved'):
+        assert hasattr(MatrixFactorization, name)
+    mf = MatrixFactorization(4, n_users=3, n_items=10)
+    assert mf.n_samples == 5 and mf.random_ind is None
+    cfg, res = None, None
+    m2 = MatrixFactorization.from_saved({'n_components': 7})
+    assert m2.n_components == 7
+
+
+def test_generic_path_matches_oracle_on_cpu(golden):
+    """Non-fast-path plug-ins (here: a dense non-identity feature matrix) train through the generic
+    autograd loop; with identity features given densely AND a subclassed loss it must equal the oracle."""
+    if torch.cuda.is_available():
+        pytest.skip('covered on the GPU box by the fast path')
+    from oracle import dense_ref as D
+    from teamoflow_amd.mf.initializer_graphs import FixedInitializer
+    from teamoflow_amd.mf.loss_graphs import MSELoss
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    from teamoflow_amd.mf.sparse import SparseInteractions
+
+    class MyMSE(MSELoss):
+        pass
+    g = golden('c1_mse')
+    m, n = g['A'].shape
+    model = MatrixFactorization(5, loss_graph=MyMSE(), user_weight_graph=FixedInitializer(g['U0']),
+                                item_weight_graph=FixedInitializer(g['V0']))
+    model.verbose = False
+    model.fit(5, torch.eye(m), torch.eye(n), SparseInteractions(g['indices'], g['values'], (m, n)), lr=float(g['lr']))
+    assert np.abs(np.array(model.loss_history_) - g['loss'][:5]).max() / g['loss'][0] < 1e-6
