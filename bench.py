@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark of the matrix-factorization training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full-batch training epoch (user pass + item pass + fresh-Adam updates + loss), the
+unit the reference times at matrix_factorization.py:129-177.  Workload = BASELINE.json's metric
+configuration: 1M users x 100K items, r = 128, WMRB with S = 1024 static negatives, ~1e8 interactions
+("C4"), fp32, synthetic data generated on the device.  With N > 1 every rank holds its
+own 1M users (weak scaling), V is replicated and its gradient is exchanged by RCCL reduce-scatter /
+all-gather (teamoflow_amd/dist.py).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from teamoflow_amd import _engine, _lib, _ops  # noqa: E402
+from teamoflow_amd import dist as tdist  # noqa: E402
+from teamoflow_amd.mf.utils import random_sampler_device  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def gen_interactions(m, n, nnz_target, items, seed, dev):
+    """Synthetic interactions of SURVEY.md §8d: user degrees lognormal(4.2, 0.8) rescaled to the
+    target; item ids from a power law (alpha = 1) over a fixed permutation ('zipf') or uniform;
+    values in {1..5}; unique row-major pairs."""
+    g = torch.Generator(device=dev).manual_seed(1000 + seed)
+    deg = torch.exp(4.2 + 0.8 * torch.randn(m, device=dev, generator=g))
+    deg = torch.clamp(torch.round(deg * (nnz_target / float(deg.sum()))), 1, n // 4).to(torch.int64)
+    total = int(deg.sum())
+    u = torch.repeat_interleave(torch.arange(m, device=dev), deg, output_size=total)
+    if items == 'zipf':
+        x = torch.rand(total, device=dev, generator=g)
+        ranks = torch.clamp(torch.pow(float(n + 1), x).to(torch.int64) - 1, 0, n - 1)
+        perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(4242))
+        j = perm[ranks]
+        del x, ranks
+    else:
+        j = torch.randint(0, n, (total,), device=dev, generator=g)
+    key = torch.unique(u * n + j)
+    del u, j
+    u, j = key // n, key % n
+    vals = torch.randint(1, 6, (key.numel(),), device=dev, generator=g).to(torch.float32)
+    return torch.stack([u, j], dim=1), vals
+
+
+def init_table(rows, r, seed, dev):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(rows, r, device=dev, generator=g)
+    return x * torch.rsqrt(torch.clamp((x * x).sum(), min=1e-12))
+
+
+def wmrb_bytes(m, n, S, P, r, s=4):
+    """Algorithmic bytes per epoch split by kernel."""
+    user = m * S * (2 * r * s + 8) + P * (r * s + 12) + m * 2 * r * s
+    item = m * S * (r * s + 8) + P * (r * s + 12) + n * 2 * r * s
+    return user, item
+
+
+def mse_bytes(m, n, nnz, r, s=4):
+    return nnz * (r * s + 12) + m * 2 * r * s, nnz * (r * s + 12) + n * 2 * r * s
+
+
+def cpu_baseline_wmrb(idx, val, R, U0, V0, n, S, lr, users=1024):
+    """The oracle's closed-form WMRB epoch (oracle/sparse_ref.py, NumPy, 1 thread of BLAS-free code) on
+    the first `users` users of the same workload - a reported baseline, never the measured path."""
+    from oracle import sparse_ref
+    rows = idx[:, 0] < users
+    sidx = idx[rows].cpu().numpy()
+    sval = val[rows].cpu().numpy()
+    Us = U0[:users].cpu().numpy()
+    Vs = V0.cpu().numpy()
+    Rs = R[:users].cpu().numpy().astype(np.int64)
+    t0 = time.perf_counter()
+    sparse_ref.wmrb_epoch(Us, Vs, sidx, sval, Rs, n, S, lr)
+    dt = time.perf_counter() - t0
+    return dict(value=len(sval) / dt, unit='interactions/s', cores=1, kind='port',
+                sample=f'one WMRB epoch of oracle/sparse_ref.py on the first {users} users of the same workload '
+                       f'({len(sval)} interactions, S={S}, r={Us.shape[1]}), {dt:.1f} s')
+
+
+def recall_parity(dev):
+    """recall@10 of the engine vs the oracle on the C1 golden case (BASELINE 'recall@10 parity')."""
+    from oracle import dense_ref
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'c1_mse.npz')))
+    model = MatrixFactorization(5)
+    model.user_embedding = torch.tensor(g['U_450']).to(dev)
+    model.item_embedding = torch.tensor(g['V_450']).to(dev)
+    got = float(model.recall_at_k(torch.tensor(g['A'])).mean())
+    want = float(dense_ref.recall_at_k_dense(g['U_450'], g['V_450'], g['A'], 10).mean())
+    return got, want
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--users', type=int, default=1_000_000)
+    ap.add_argument('--items', type=int, default=100_000)
+    ap.add_argument('--rank', type=int, default=128, dest='r')
+    ap.add_argument('--nnz', type=int, default=100_000_000)
+    ap.add_argument('--samples', type=int, default=1024)
+    ap.add_argument('--loss', choices=['wmrb', 'mse'], default='wmrb')
+    ap.add_argument('--item-dist', choices=['zipf', 'uniform'], default='zipf')
+    ap.add_argument('--lr', type=float, default=0.1)
+    ap.add_argument('--no-extras', action='store_true', help='skip cpu baseline / predict / mse side measurements')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)
+    _lib.get()
+
+    m, n, r, S = args.users, args.items, args.r, args.samples
+    t_prep = time.perf_counter()
+    idx, val = gen_interactions(m, n, args.nnz, args.item_dist, rank, dev)
+    nnz = int(val.numel())
+    n_pad = tdist.padded_rows(n, world)
+    U0 = init_table(m, r, 11 + rank, dev)
+    V0 = torch.zeros(n_pad, r, device=dev)
+    V0[:n] = init_table(n, r, 7, dev)  # identical on every rank
+    plan = _engine.InteractionPlan(idx, val, m, n_pad)
+    wplan, R = None, None
+    if args.loss == 'wmrb':
+        R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
+        wplan = _engine.WmrbPlan(plan, R)
+    st = _engine.TrainState(U0, V0, plan, r, wplan)
+    adam = _engine.adam_constants(args.lr)
+    c = n / S
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f'[bench] prepared {nnz} interactions, m={m} n={n} r={r} S={S} in {time.perf_counter() - t_prep:.1f} s; '
+            f'{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak')
+
+    prof = _engine.KernelTimer()
+    loss_buf = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
+    if world > 1:
+        backend = tdist.HipBackend(st, args.loss, c, adam, prof=None)
+        dp = tdist.DataParallelEpoch(backend, plan.n_pos if args.loss == 'wmrb' else nnz)
+
+    def step(i, p):
+        if world > 1:
+            backend.prof = p
+            loss_buf[i] = dp.step()
+        else:
+            if args.loss == 'wmrb':
+                _engine.epoch_wmrb(st, adam, c, loss_buf[i:i + 1], prof=p)
+            else:
+                _engine.epoch_mse(st, adam, loss_buf[i:i + 1], prof=p)
+            st.swap()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, None)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, prof)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+        tot = torch.tensor([float(nnz)], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tot)
+        nnz_total = float(tot)
+    else:
+        nnz_total = float(nnz)
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # dominant kernel + roofline (HIP events on the launch stream, inside the timed region)
+    if args.loss == 'wmrb':
+        ub, ib = wmrb_bytes(m, n, S, plan.n_pos, r)
+        kname, kbytes = 'wmrb_user_pass', ub
+        kms = prof.mean_ms('wmrb_user_pass')
+        other = {'wmrb_item_pass_ms': prof.mean_ms('wmrb_item_pass'), 'wmrb_item_pass_alg_bytes': ib}
+    else:
+        ub, ib = mse_bytes(m, n, nnz, r)
+        kname, kbytes = 'mse_item_pass', ib
+        kms = prof.mean_ms('mse_item_pass')
+        other = {'mse_user_pass_ms': prof.mean_ms('mse_user_pass'), 'mse_user_pass_alg_bytes': ub}
+    achieved = kbytes / (kms * 1e-3) / 1e9
+    roofline = dict(bound='hbm', kernel=kname, achieved=achieved, peak=HBM_PEAK / 1e9, unit='GB/s',
+                    frac=achieved / (HBM_PEAK / 1e9), traffic=None, kernel_ms=kms, alg_bytes_per_launch=kbytes,
+                    epoch_alg_bytes=ub + ib, epoch_frac=(ub + ib) / (ms_per_step * 1e-3) / HBM_PEAK, **other)
+
+    out = dict(metric='train_interactions_per_sec', value=nnz_total / (elapsed / args.steps), unit='interactions/s',
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+               scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload=f'C4: {m} users x {n} items per GPU, r={r}, {args.loss.upper()}'
+                                    + (f' S={S}' if args.loss == 'wmrb' else '') + f', item ids {args.item_dist}, '
+                                    f'lognormal user degrees', interactions_per_gpu=nnz, positives_per_gpu=plan.n_pos,
+                           parallelism=f'user-partition dp{world}', lr=args.lr),
+               roofline=roofline)
+
+    if rank == 0 and not args.no_extras and world == 1:
+        losses = loss_buf[:args.steps + args.warmup].cpu().numpy() / (plan.n_pos if args.loss == 'wmrb' else nnz)
+        out['loss_first_last'] = [float(losses[0]), float(losses[-1])]
+        if args.loss == 'wmrb':
+            out['cpu_baseline'] = cpu_baseline_wmrb(idx, val, R, U0, V0[:n], n, S, args.lr)
+        # predict rows/s: top-10 over the full catalog for a bounded number of user blocks
+        blk = max(1, min(m, (1 << 30) // (4 * n)))
+        nblk = min(4, (m + blk - 1) // blk)
+        Ue, Ve = st.U[:, :r], st.V[:n, :r]
+        scores = torch.empty(blk, n, device=dev)
+        _ops.topk_stable(_ops.predict_gemm(Ue[:blk], Ve, out=scores), 10, clamp_negatives=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for b in range(nblk):
+            rows = min(blk, m - b * blk)
+            _ops.topk_stable(_ops.predict_gemm(Ue[b * blk:b * blk + rows], Ve, out=scores[:rows]), 10, clamp_negatives=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        out['predict_rows_per_sec'] = min(nblk * blk, m) / dt
+        out['predict_note'] = f'full-catalog scores + stable top-10 for {min(nblk * blk, m)} users in blocks of {blk}'
+        got, want = recall_parity(dev)
+        out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want), case='C1 golden fixture')
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -35,7 +35,7 @@ def adam_fresh(w, g, lr):
 
 
 def mse_epoch(U, V, indices, values, lr):
-    """Returns (U_new, V_new, mean_loss, per_interaction_loss)."""
+    """Returns (U_new, V_new, mean_loss, terms) with terms = dict(loss, delta, gU, gV)."""
     u, j = indices[:, 0], indices[:, 1]
     a = values.astype(U.dtype)
     p = np.einsum('kc,kc->k', U[u], V[j]).astype(U.dtype)
@@ -46,7 +46,8 @@ def mse_epoch(U, V, indices, values, lr):
     gV = np.zeros_like(V)
     np.add.at(gU, u, d[:, None] * V[j])
     np.add.at(gV, j, d[:, None] * U[u])
-    return adam_fresh(U, gU, lr), adam_fresh(V, gV, lr), float(loss.astype(np.float64).mean()), loss
+    mean = float(loss.astype(np.float64).mean()) if len(loss) else float('nan')
+    return adam_fresh(U, gU, lr), adam_fresh(V, gV, lr), mean, dict(loss=loss, delta=d, gU=gU, gV=gV)
 
 
 def wmrb_terms(U, V, indices, values, R, n_items, n_samples):

@@ -148,42 +148,80 @@ class TrainState:
         self.V, self.V_nxt = self.V_nxt, self.V
 
 
+class KernelTimer:
+    """HIP-event brackets around named launches on the current stream (bench.py uses it to get the
+    dominant kernel's own duration inside the timed region)."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def start(self, name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.spans.setdefault(name, []).append([ev, None])
+
+    def stop(self, name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.spans[name][-1][1] = ev
+
+    def mean_ms(self, name):
+        v = [a.elapsed_time(b) for a, b in self.spans.get(name, []) if b is not None]
+        return sum(v) / len(v) if v else float('nan')
+
+
 def _row_pass_finish(lib, seg, slab, X_old, X_out, r, epi, adam, stream):
     if seg.n_long:
         _lib.check(lib.tmf_combine_rows_f32(_lib.ptr(seg.long_rows), _lib.ptr(seg.long_slab_beg), seg.n_long,
                                             _lib.ptr(slab), _lib.ptr(X_old), _lib.ptr(X_out), r, epi, adam, stream), lib)
 
 
-def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None):
+def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):
     """One MSE epoch: user pass (+loss), item pass; both read the pre-update tables.
     loss_out: 1-element fp64 device tensor receiving sum_k (a_k - p_k)^2.
     item_epi=EPI_GRAD writes the raw item gradient into item_out (multi-GPU)."""
     lib, p, r = _lib.get(), st.plan, st.r
     s = _lib.stream_ptr()
+    if prof:
+        prof.start('mse_user_pass')
     _lib.check(lib.tmf_mse_pass_f32(p.seg_u.cstruct(), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.U),
                                     _lib.ptr(st.V), _lib.ptr(st.U_nxt), _lib.ptr(st.slab), _lib.ptr(st.loss_part),
                                     r, _lib.EPI_ADAM, adam, s), lib)
+    if prof:
+        prof.stop('mse_user_pass')
     _row_pass_finish(lib, p.seg_u, st.slab, st.U, st.U_nxt, r, _lib.EPI_ADAM, adam, s)
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.seg_u.nseg, _lib.ptr(loss_out), s), lib)
     V_out = st.V_nxt if item_out is None else item_out
+    if prof:
+        prof.start('mse_item_pass')
     _lib.check(lib.tmf_mse_pass_f32(p.seg_i.cstruct(), _lib.ptr(p.row_i), _lib.ptr(p.val_i), _lib.ptr(st.V),
                                     _lib.ptr(st.U), _lib.ptr(V_out), _lib.ptr(st.slab), None, r, item_epi, adam, s), lib)
+    if prof:
+        prof.stop('mse_item_pass')
     _row_pass_finish(lib, p.seg_i, st.slab, st.V, V_out, r, item_epi, adam, s)
 
 
-def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None):
+def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):
     """One WMRB epoch.  loss_out receives sum over positives of log(1 + M_k)."""
     lib, p, w, r = _lib.get(), st.plan, st.wplan, st.r
     s = _lib.stream_ptr()
+    if prof:
+        prof.start('wmrb_user_pass')
     _lib.check(lib.tmf_wmrb_user_pass_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
                                           p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
                                           _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None, r,
                                           _lib.EPI_ADAM, adam, s), lib)
+    if prof:
+        prof.stop('wmrb_user_pass')
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)
     V_out = st.V_nxt if item_out is None else item_out
+    if prof:
+        prof.start('wmrb_item_pass')
     _lib.check(lib.tmf_wsum_pass_f32(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf),
                                      _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(V_out), _lib.ptr(st.slab), r, item_epi,
                                      adam, s), lib)
+    if prof:
+        prof.stop('wmrb_item_pass')
     _row_pass_finish(lib, w.seg_e, st.slab, st.V, V_out, r, item_epi, adam, s)
 
 

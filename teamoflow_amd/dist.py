@@ -1,0 +1,105 @@
+"""User-partitioned data parallelism over the GPUs of one node.
+
+The reference is single-process; this is the one exchange step its algorithm has when users are
+split across ranks.  Rank g owns a contiguous block of users: its rows of U, its interactions, its
+rows of the negative table R and of D.  U is never communicated.  V is replicated for compute and
+row-sharded for the optimiser:
+
+    user pass            local (HIP)                         U_blk <- fresh-Adam(U_blk, gU_blk)
+    item pass            local (HIP, gradient epilogue)      gV_partial [n_pad, ld]
+    reduce-scatter(sum)  RCCL over xGMI                      gV_shard   [n_pad / G, ld]
+    fresh-Adam           local (HIP) on the owned V rows     the step is non-linear in g, so the sum
+                                                             must complete before any update
+    all-gather           RCCL, in place                      V [n_pad, ld] replicated again
+    all-reduce           2 doubles                           (sum of losses, count)
+
+The compute is injected (``backend``) so the choreography can be exercised with gloo on CPU
+(tests/test_dist_cpu.py drives it with the NumPy oracle); on the GPU the backend is ``HipBackend``.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _engine, _lib
+
+
+def partition_users(rowptr, world_size, per_user_cost=0):
+    """Contiguous user blocks with balanced cost; cost(u) = #interactions(u) + per_user_cost
+    (per_user_cost = n_samples for WMRB).  Returns world_size + 1 boundaries."""
+    rowptr = torch.as_tensor(rowptr).to(torch.int64).cpu()
+    m = rowptr.numel() - 1
+    cost = (rowptr[1:] - rowptr[:-1]) + int(per_user_cost)
+    cum = torch.cumsum(cost, 0)
+    total = int(cum[-1]) if m else 0
+    bounds = [0]
+    for g in range(1, world_size):
+        target = total * g // world_size
+        b = int(torch.searchsorted(cum, torch.tensor(target), right=False)) + 1 if m else 0
+        bounds.append(min(max(b, bounds[-1]), m))
+    bounds.append(m)
+    return bounds
+
+
+def padded_rows(n, world_size):
+    return (n + world_size - 1) // world_size * world_size
+
+
+class HipBackend:
+    """Local compute of one rank on the HIP engine.  ``st`` is an _engine.TrainState whose V tables
+    have n_pad rows (rows >= n_items have no interactions and stay zero)."""
+
+    def __init__(self, st, loss, c, adam, prof=None):
+        self.st, self.loss, self.c, self.adam, self.prof = st, loss, c, adam, prof
+        dev = st.V.device
+        self.gV = torch.empty_like(st.V)
+        self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def local_passes(self):
+        """U block updated into st.U_nxt; raw item gradient of this rank's users into self.gV."""
+        if self.loss == 'wmrb':
+            _engine.epoch_wmrb(self.st, self.adam, self.c, self.loss_out, _lib.EPI_GRAD, self.gV, self.prof)
+        else:
+            _engine.epoch_mse(self.st, self.adam, self.loss_out, _lib.EPI_GRAD, self.gV, self.prof)
+        return self.gV, self.loss_out
+
+    def adam_rows(self, W_rows, G_rows):
+        lib = _lib.get()
+        _lib.check(lib.tmf_adam_fresh_rows_f32(_lib.ptr(W_rows), _lib.ptr(G_rows), W_rows.shape[0], self.st.r,
+                                               self.adam, _lib.stream_ptr()), lib)
+
+    def V(self):
+        return self.st.V
+
+    def finish(self):
+        self.st.U, self.st.U_nxt = self.st.U_nxt, self.st.U
+
+
+class DataParallelEpoch:
+    """One epoch across the process group.  Collectives run on torch.distributed's default group
+    ('nccl' = RCCL on the GPU box, 'gloo' in the CPU tests)."""
+
+    def __init__(self, backend, local_count, group=None):
+        self.b = backend
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        V = backend.V()
+        if V.shape[0] % self.world:
+            raise ValueError(f'V has {V.shape[0]} rows, not a multiple of world_size={self.world}')
+        self.rows_per_rank = V.shape[0] // self.world
+        self.g_shard = torch.empty(self.rows_per_rank, V.shape[1], dtype=V.dtype, device=V.device)
+        self.stats = torch.zeros(2, dtype=torch.float64, device=V.device)
+        self.local_count = float(local_count)
+
+    def step(self):
+        """Returns the global mean loss as a 0-d fp64 tensor (no host sync)."""
+        gV, loss_sum = self.b.local_passes()
+        dist.reduce_scatter_tensor(self.g_shard, gV, op=dist.ReduceOp.SUM, group=self.group)
+        V = self.b.V()
+        mine = V[self.rank * self.rows_per_rank:(self.rank + 1) * self.rows_per_rank]
+        self.b.adam_rows(mine, self.g_shard)
+        dist.all_gather_into_tensor(V, mine, group=self.group)
+        self.stats[0] = loss_sum.reshape(())
+        self.stats[1] = self.local_count
+        dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
+        self.b.finish()
+        return self.stats[0] / self.stats[1]

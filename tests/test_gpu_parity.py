@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
 committed golden fixtures.  Tolerances: indices / top-k bit-exact; loss, gradients and predictions
-1e-5 relative (norm-wise, fp32); factor tables per conftest.weights_close."""
+1e-5 relative (norm-wise, fp32); factor tables after a step per conftest.step_bounds (the interval the
+reference's update spans for a gradient within 1e-5 of the oracle's fp64 closed form)."""
 import importlib.util
 import os
 
@@ -8,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, rel_err, weights_close
+from conftest import GOLDEN, assert_step, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -49,30 +50,45 @@ def fit_model(tm, U0, V0, idx, val, shape, epochs, lr, loss='mse', R=None, n_ite
     return model
 
 
+def check_one_step(tm, U0, V0, idx, val, shape, lr, loss='mse', R=None, n_items=None, n_samples=None, fixture=None):
+    """One epoch on the GPU from (U0, V0) against the fp64 closed form: mean loss to 1e-5, both tables
+    inside the step interval.  ``fixture`` = (U_1, V_1) from the committed golden file (dense fp32 oracle)
+    must lie in the same interval.  Returns (model, oracle terms)."""
+    from oracle import sparse_ref as S
+    model = fit_model(tm, U0, V0, idx, val, shape, 1, lr, loss, R, n_items, n_samples)
+    U64, V64 = np.asarray(U0, np.float64), np.asarray(V0, np.float64)
+    idx = np.asarray(idx, np.int64)
+    if loss == 'mse':
+        _, _, mean, t = S.mse_epoch(U64, V64, idx, np.asarray(val, np.float64), lr)
+    else:
+        _, _, mean, t = S.wmrb_epoch(U64, V64, idx, np.asarray(val, np.float64), np.asarray(R), n_items, n_samples, lr)
+    if np.isfinite(mean):
+        assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean), (model.loss_history_[0], mean)
+    assert_step(model.user_embedding.cpu().numpy(), U0, t['gU'], lr, what=f'{loss} U')
+    assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], lr, what=f'{loss} V')
+    if fixture is not None:
+        assert_step(fixture[0], U0, t['gU'], lr, what=f'{loss} fixture U')
+        assert_step(fixture[1], V0, t['gV'], lr, what=f'{loss} fixture V')
+    return model, t
+
+
 def test_gather_matrix_indices_known_answer(tm, golden):
     g = golden('gather_known_answer')
     out = tm.utils.gather_matrix_indices(torch.tensor(g['input']), torch.tensor(g['index']))
     assert np.array_equal(out.cpu().numpy(), g['expected'])
 
 
-def test_c1_mse_trajectory_and_ranking(tm, golden):
+def test_c1_mse_trajectory_and_steps(tm, golden):
     g = golden('c1_mse')
-    lr = float(g['lr'])
-    model = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 25, lr)
-    assert rel_err(model.loss_history_, g['loss'][:25]) < 1e-5
-    ok, err, tol = weights_close(model.user_embedding.cpu().numpy(), g['U_25'], lr, frac_lr=0.25)
-    assert ok, (err, tol)
-    one = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 1, lr)
-    for got, want in ((one.user_embedding, g['U_1']), (one.item_embedding, g['V_1'])):
-        ok, err, tol = weights_close(got.cpu().numpy(), want, lr)
-        assert ok, (err, tol)
-    # teacher-forced single steps from the oracle's own state late in training
-    two = fit_model(tm, g['U_25'], g['V_25'], g['indices'], g['values'], g['A'].shape, 1, lr)
-    from oracle import sparse_ref as S
-    Uw, Vw, lw, _ = S.mse_epoch(g['U_25'], g['V_25'], g['indices'], g['values'], lr)
-    assert abs(two.loss_history_[0] - lw) / lw < 1e-5
-    assert weights_close(two.user_embedding.cpu().numpy(), Uw, lr)[0]
-    assert weights_close(two.item_embedding.cpu().numpy(), Vw, lr)[0]
+    lr, shape = float(g['lr']), g['A'].shape
+    model = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], shape, 450, lr)
+    assert rel_err(model.loss_history_[:25], g['loss'][:25]) < 1e-5
+    assert rel_err(model.loss_history_, g['loss']) < 1e-3  # 450 near-sign Adam steps amplify fp32 reordering
+    # single steps from the initial state and (teacher-forced) from the oracle's own later states
+    for e in (0, 1, 25, 450):
+        U, V = (g['U0'], g['V0']) if e == 0 else (g[f'U_{e}'], g[f'V_{e}'])
+        check_one_step(tm, U, V, g['indices'], g['values'], shape, lr)
+    check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], shape, lr, fixture=(g['U_1'], g['V_1']))
 
 
 def test_c1_full_run_predict_topk_recall(tm, golden):
@@ -105,9 +121,7 @@ def test_c2_mse(tm, golden):
     model = fit_model(tm, U0, V0, idx, val, A.shape, 100, lr)
     assert rel_err(model.loss_history_[:10], g['loss'][:10]) < 1e-5
     assert rel_err(model.loss_history_, g['loss']) < 1e-4  # 100 near-sign Adam steps amplify rounding
-    one = fit_model(tm, U0, V0, idx, val, A.shape, 1, lr)
-    assert weights_close(one.user_embedding.cpu().numpy(), g['U_1'], lr)[0]
-    assert weights_close(one.item_embedding.cpu().numpy(), g['V_1'], lr)[0]
+    check_one_step(tm, U0, V0, idx, val, A.shape, lr, fixture=(g['U_1'], g['V_1']))
     rec = float(model.recall_at_k(torch.tensor(A)).mean())
     assert abs(rec - float(g['recall10_mean'])) <= 1e-3
 
@@ -121,11 +135,9 @@ def test_wmrb_fixtures(tm, golden, name):
                       n_samples)
     assert rel_err(model.loss_history_[:3], g['loss'][:3]) < 1e-5
     assert rel_err(model.loss_history_, g['loss']) < 2e-3
-    one = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 1, lr, 'wmrb', g['R'], n_items,
-                    n_samples)
-    for got, want in ((one.user_embedding, g['U_1']), (one.item_embedding, g['V_1'])):
-        ok, err, tol = weights_close(got.cpu().numpy(), want, lr)
-        assert ok, (name, err, tol)
+    one, _ = check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, lr, 'wmrb', g['R'], n_items,
+                            n_samples, fixture=(g['U_1'], g['V_1']))
+    check_one_step(tm, g[f'U_{E}'], g[f'V_{E}'], g['indices'], g['values'], g['A'].shape, lr, 'wmrb', g['R'], n_items, n_samples)
     if name == 'wmrb_small':
         st = one._state
         assert rel_err(st.wplan.D.cpu().numpy(), g['D_first']) < 1e-5
@@ -140,14 +152,11 @@ def test_c3r_wmrb(tm, golden):
     lr = float(g['lr'])
     model = fit_model(tm, U0, V0, idx, val, A.shape, 3, lr, 'wmrb', R, n, n // 2)
     assert rel_err(model.loss_history_, g['loss'][:3]) < 1e-5
-    one = fit_model(tm, U0, V0, idx, val, A.shape, 1, lr, 'wmrb', R, n, n // 2)
-    assert weights_close(one.user_embedding.cpu().numpy(), g['U_1'], lr)[0]
-    assert weights_close(one.item_embedding.cpu().numpy(), g['V_1'], lr)[0]
+    check_one_step(tm, U0, V0, idx, val, A.shape, lr, 'wmrb', R, n, n // 2, fixture=(g['U_1'], g['V_1']))
 
 
 @pytest.mark.parametrize('r', [1, 3, 4, 7, 16, 33, 64, 100, 128, 200, 256, 300, 512])
 def test_every_rank_geometry_mse_and_wmrb(tm, r):
-    from oracle import sparse_ref as S
     rng = np.random.default_rng(r)
     m, n, S_ = 37, 29, 11
     A = (rng.random((m, n)) < 0.2) * rng.integers(-2, 6, (m, n))
@@ -157,22 +166,13 @@ def test_every_rank_geometry_mse_and_wmrb(tm, r):
     V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
     R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
     lr = 0.01
-    mse = fit_model(tm, U0, V0, idx, val, (m, n), 1, lr)
-    Uw, Vw, lw, _ = S.mse_epoch(U0, V0, idx, val, lr)
-    assert abs(mse.loss_history_[0] - lw) / lw < 1e-5
-    assert weights_close(mse.user_embedding.cpu().numpy(), Uw, lr)[0]
-    assert weights_close(mse.item_embedding.cpu().numpy(), Vw, lr)[0]
-    w = fit_model(tm, U0, V0, idx, val, (m, n), 1, lr, 'wmrb', R, n, S_)
-    Uw, Vw, lw, t = S.wmrb_epoch(U0, V0, idx, val, R, n, S_, lr)
-    assert abs(w.loss_history_[0] - lw) / lw < 1e-5
-    assert weights_close(w.user_embedding.cpu().numpy(), Uw, lr)[0]
-    assert weights_close(w.item_embedding.cpu().numpy(), Vw, lr)[0]
+    check_one_step(tm, U0, V0, idx, val, (m, n), lr)
+    w, t = check_one_step(tm, U0, V0, idx, val, (m, n), lr, 'wmrb', R, n, S_)
     assert rel_err(w._state.wplan.D.cpu().numpy(), t['D']) < 1e-5
 
 
 def test_heavy_rows_are_segmented_and_combined(tm):
     """Rows longer than the segment length go through the slab + combine path."""
-    from oracle import sparse_ref as S
     rng = np.random.default_rng(7)
     m, n, r = 6, 5000, 32
     A = np.zeros((m, n), np.float32)
@@ -184,28 +184,19 @@ def test_heavy_rows_are_segmented_and_combined(tm):
     val = A[A != 0]
     U0 = (rng.standard_normal((m, r)) * 0.1).astype(np.float32)
     V0 = (rng.standard_normal((n, r)) * 0.1).astype(np.float32)
-    model = fit_model(tm, U0, V0, idx, val, (m, n), 1, 0.01)
+    model, _ = check_one_step(tm, U0, V0, idx, val, (m, n), 0.01)
     assert model._state.plan.seg_u.n_long == 2 and model._state.plan.seg_u.n_slab == 5 + 2
-    Uw, Vw, lw, _ = S.mse_epoch(U0, V0, idx, val, 0.01)
-    assert abs(model.loss_history_[0] - lw) / lw < 1e-5
-    assert weights_close(model.user_embedding.cpu().numpy(), Uw, 0.01)[0]
-    assert weights_close(model.item_embedding.cpu().numpy(), Vw, 0.01)[0]
     assert np.array_equal(model.user_embedding.cpu().numpy()[3], U0[3])  # user without interactions: untouched
 
 
 def test_unsorted_and_duplicate_interactions(tm):
-    from oracle import sparse_ref as S
     rng = np.random.default_rng(11)
     m, n, r = 20, 30, 8
     idx = np.stack([rng.integers(0, m, 200), rng.integers(0, n, 200)], axis=1)  # unsorted, with duplicates
     val = rng.integers(1, 6, 200).astype(np.float32)
     U0 = (rng.standard_normal((m, r)) * 0.2).astype(np.float32)
     V0 = (rng.standard_normal((n, r)) * 0.2).astype(np.float32)
-    model = fit_model(tm, U0, V0, idx, val, (m, n), 1, 0.01)
-    Uw, Vw, lw, _ = S.mse_epoch(U0, V0, idx, val, 0.01)
-    assert abs(model.loss_history_[0] - lw) / lw < 1e-5
-    assert weights_close(model.user_embedding.cpu().numpy(), Uw, 0.01)[0]
-    assert weights_close(model.item_embedding.cpu().numpy(), Vw, 0.01)[0]
+    check_one_step(tm, U0, V0, idx, val, (m, n), 0.01)
 
 
 def test_empty_interactions_leave_tables_unchanged(tm):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import torch
 
-from conftest import GOLDEN, rel_err, weights_close
+from conftest import GOLDEN, assert_step, rel_err
 from oracle import datagen as G
 from oracle import dense_ref as D
 from oracle import sparse_ref as S
@@ -105,7 +105,11 @@ def test_fixture_c2_inputs_regenerate(golden):
     assert sha(U0) == str(g['U0_sha']) and sha(V0) == str(g['V0_sha'])
     s = S.mse_epoch(U0, V0, idx, val, float(g['lr']))
     assert abs(s[2] - g['loss'][0]) / g['loss'][0] < 1e-6
-    assert weights_close(s[0], g['U_1'], 1e-3)[0] and weights_close(s[1], g['V_1'], 1e-3)[0]
+    s64 = S.mse_epoch(U0.astype(np.float64), V0.astype(np.float64), idx, val.astype(np.float64), float(g['lr']))
+    for got in (s[0], g['U_1']):
+        assert_step(got, U0, s64[3]['gU'], float(g['lr']))
+    for got in (s[1], g['V_1']):
+        assert_step(got, V0, s64[3]['gV'], float(g['lr']))
 
 
 def test_recall_dense_vs_sparse(golden):
