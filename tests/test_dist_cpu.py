@@ -1,0 +1,112 @@
+"""world_size-2 gloo test of the data-parallel epoch (teamoflow_amd/dist.py) on CPU.
+
+The HIP engine cannot run here, so the local compute is injected: a backend that evaluates the
+oracle's closed forms for this rank's user block.  What is under test is the N>1 choreography -
+user partition, raw item gradient -> reduce-scatter -> fresh-Adam on the owned rows -> in-place
+all-gather -> loss all-reduce - which must reproduce the single-process oracle epoch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+class OracleBackend:
+    def __init__(self, U_blk, V_pad, idx_local, val, R_blk, n_items, n_samples, lr, loss):
+        self.U, self.Vt = U_blk.copy(), torch.tensor(V_pad)
+        self.idx, self.val, self.R = idx_local, val, R_blk
+        self.n_items, self.n_samples, self.lr, self.loss = n_items, n_samples, lr, loss
+
+    def V(self):
+        return self.Vt
+
+    def local_passes(self):
+        from oracle import sparse_ref as S
+        V = self.Vt.numpy().copy()
+        if self.loss == 'mse':
+            U_new, _, _, t = S.mse_epoch(self.U, V, self.idx, self.val, self.lr)
+            loss_sum = float(t['loss'].astype(np.float64).sum())
+        else:
+            U_new, _, _, t = S.wmrb_epoch(self.U, V, self.idx, self.val, self.R, self.n_items, self.n_samples, self.lr)
+            loss_sum = float(t['loss'].astype(np.float64).sum())
+        self.U_new = U_new
+        return torch.tensor(t['gV']), torch.tensor([loss_sum], dtype=torch.float64)
+
+    def adam_rows(self, W_rows, G_rows):
+        from oracle import sparse_ref as S
+        W_rows.copy_(torch.tensor(S.adam_fresh(W_rows.numpy().copy(), G_rows.numpy(), self.lr)))
+
+    def finish(self):
+        self.U = self.U_new
+
+
+def _worker(rank, world, port, loss, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import sparse_ref as S
+    from teamoflow_amd import dist as tdist
+    rng = np.random.default_rng(0)
+    m, n, r, Sn, lr = 23, 17, 6, 5, 0.05
+    A = (rng.random((m, n)) < 0.3) * rng.integers(1, 6, (m, n))
+    idx = np.argwhere(A != 0)
+    val = A[A != 0].astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, Sn, replace=False) for _ in range(m)])
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(idx[:, 0], minlength=m))])
+    bounds = tdist.partition_users(rowptr, world, per_user_cost=Sn if loss == 'wmrb' else 0)
+    b, e = bounds[rank], bounds[rank + 1]
+    sel = (idx[:, 0] >= b) & (idx[:, 0] < e)
+    idx_l = idx[sel].copy()
+    idx_l[:, 0] -= b
+    n_pad = tdist.padded_rows(n, world)
+    V_pad = np.zeros((n_pad, r), np.float32)
+    V_pad[:n] = V0
+    backend = OracleBackend(U0[b:e], V_pad, idx_l, val[sel], R[b:e], n, Sn, lr, loss)
+    dp = tdist.DataParallelEpoch(backend, local_count=int(sel.sum()))
+    losses = [float(dp.step()) for _ in range(3)]
+    # single-process oracle
+    U, V = U0.copy(), V0.copy()
+    ref_losses = []
+    for _ in range(3):
+        if loss == 'mse':
+            U, V, l, _ = S.mse_epoch(U, V, idx, val, lr)
+        else:
+            U, V, l, _ = S.wmrb_epoch(U, V, idx, val, R, n, Sn, lr)
+        ref_losses.append(l)
+    ok = (np.allclose(losses, ref_losses, rtol=1e-5)
+          and np.abs(backend.U - U[b:e]).max() < 5e-3 * lr + 1e-6
+          and np.abs(backend.V().numpy()[:n] - V).max() < 5e-2 * lr + 1e-6
+          and np.all(backend.V().numpy()[n:] == 0))
+    # V must be identical on every rank after the all-gather
+    Vall = [torch.zeros_like(backend.V()) for _ in range(world)]
+    dist.all_gather(Vall, backend.V())
+    ok = ok and all(torch.equal(Vall[0], v) for v in Vall)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+def test_data_parallel_epoch_matches_single_process(loss):
+    world = 2
+    port = 29600 + (os.getpid() % 200) + (0 if loss == 'mse' else 1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, loss, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)), dict(out)
+
+
+def test_partition_users_balances_cost():
+    from teamoflow_amd.dist import padded_rows, partition_users
+    rowptr = np.concatenate([[0], np.cumsum([100, 1, 1, 1, 100, 1, 1, 95])])
+    assert partition_users(rowptr, 2) == [0, 4, 8] or partition_users(rowptr, 2) == [0, 5, 8]
+    b = partition_users(rowptr, 3, per_user_cost=10)
+    assert b[0] == 0 and b[-1] == 8 and all(x <= y for x, y in zip(b, b[1:]))
+    assert partition_users(np.array([0]), 4) == [0, 0, 0, 0, 0]
+    assert padded_rows(100000, 8) == 100000 and padded_rows(10, 4) == 12
