@@ -130,6 +130,14 @@ int tmf_predict_gemm_f32(const float* A, const float* B, float* C, int64_t m, in
 int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, int k,
                         int clamp_negatives, int32_t* out_idx, float* out_val, void* stream);
 
+/* K7+K8 fused: out_idx[u, :k] = top-k (value desc, index asc) of A[u, :r] . B[:, :r]^T over all n items,
+ * without materialising the [m, n] scores (recall_at_k / retrieve_user_recs, matrix_factorization.py:236-248,
+ * :424-438, at catalog sizes where the dense matrix does not fit).  Supports k <= 32 and r <= 128; returns
+ * TMF_E_UNSUPPORTED otherwise (callers then score block-wise with tmf_predict_gemm_f32 + tmf_topk_stable_f32). */
+int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
+                         int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,7 @@ SIGNATURES = {
     'tmf_gather_rows_cols_f32': (_I, [_P, _P, _P, _L, _L, _L, _P]),
     'tmf_predict_gemm_f32': (_I, [_P, _P, _P, _L, _L, _I, _L, _L, _L, _P]),
     'tmf_topk_stable_f32': (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
+    'tmf_predict_topk_f32': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P]),
 }
 
 _lib = None

@@ -42,6 +42,27 @@ def predict_gemm(user_embedding, item_embedding, out=None):
     return out
 
 
+FUSED_MAX_K, FUSED_MAX_R = 32, 128
+
+
+def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False):
+    """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
+    Only for k <= 32 and width <= 128; see topk_stable(predict_gemm(...)) for the general case."""
+    lib = _lib.get()
+    A, m, r, lda = _gemm_operand(user_embedding)
+    B, n, rb, ldb = _gemm_operand(item_embedding)
+    if r != rb:
+        raise ValueError(f'embedding widths differ: {r} vs {rb}')
+    k = int(k)
+    if not 1 <= k <= n:
+        raise ValueError(f'k={k} must be in [1, {n}]')
+    idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
+    vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
+    _lib.check(lib.tmf_predict_topk_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
+                                        _lib.ptr(idx), _lib.ptr(vals), _lib.stream_ptr()), lib)
+    return (vals, idx) if return_values else idx
+
+
 def topk_stable(x, k, clamp_negatives=False, return_values=False):
     """Row-wise top-k indices (int32) ordered like tf.math.top_k: value desc, ties -> lower index."""
     lib = _lib.get()

@@ -281,3 +281,231 @@ extern "C" int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, floa
                        (hipStream_t)stream, X, idx, out, rows, cols, k);
     return check_launch("tmf_gather_rows_cols_f32");
 }
+
+// =============================================================================================
+// K7+K8 fused: top-k of U.V^T per user without materialising the [m, n] score matrix
+// (recall_at_k / retrieve_user_recs at catalog sizes where 4*m*n bytes do not fit).
+//
+// One 256-thread workgroup owns 128 users, 32 per wave.  Their rows live in REGISTERS as MFMA A fragments
+// for the whole kernel (K/2 floats per lane); item tiles of 128 stream through a 3-slot LDS ring in
+// k-chunks of 32 (global loads for chunk g+2 are issued before the MFMAs of chunk g and written to
+// LDS after them, one barrier per chunk).  After each 128x128 tile every lane tests its 64
+// accumulator values against the per-row threshold (the row's current k-th best, in LDS) and pushes
+// the few that pass into a per-row pending buffer; one thread per row then merges them into the
+// row's sorted list under the total order (value desc, index asc).  Items arrive in ascending index
+// order, so "strictly greater than the k-th value" is exactly tf.math.top_k's tie rule.  If a row
+// gets more candidates than the pending buffer holds (always on the first tile, when the threshold
+// is -inf), the tile is re-offered in 8 column groups of 16 - same result, no extra memory.
+// =============================================================================================
+namespace tmf {
+
+constexpr int FBM = 128, FBN = 128, FBK = 32, FLD = FBN + 1, FCAP = 16, FMAXK = 32;
+
+template <int NCH>  // K_PAD = 32 * NCH
+__global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict__ A, const float* __restrict__ B,
+                                                         int64_t m, int64_t n, int K, int64_t lda, int64_t ldb, int k,
+                                                         int clamp, int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_val) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Bs = reinterpret_cast<float*>(smem_raw);          // [3][FBK][FLD]
+    float* tau = Bs + 3 * FBK * FLD;                         // [FBM]
+    int* cnt = reinterpret_cast<int*>(tau + FBM);            // [FBM]
+    int* ovf = cnt + FBM;                                    // [4] (one word used)
+    float* pend_v = reinterpret_cast<float*>(ovf + 4);       // [FCAP][FBM]
+    int* pend_i = reinterpret_cast<int*>(pend_v + FCAP * FBM);
+    float* list_v = reinterpret_cast<float*>(pend_i + FCAP * FBM);  // [k][FBM]
+    int* list_i = reinterpret_cast<int*>(list_v + (size_t)k * FBM);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * FBM;
+
+    // ---- A fragments of this wave's 32 users: a[kk] = U[row0 + 32 wave + l31][2 kk + h] ----
+    float a[16 * NCH];
+    {
+        const int64_t r = row0 + 32 * wave + l31;
+        const float* p = A + (r < m ? r : 0) * lda;
+#pragma unroll
+        for (int q = 0; q < 8 * NCH; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < m) {
+                if (4 * q + 3 < K) v = *reinterpret_cast<const float4*>(p + 4 * q);
+                else { if (4 * q < K) v.x = p[4 * q]; if (4 * q + 1 < K) v.y = p[4 * q + 1]; if (4 * q + 2 < K) v.z = p[4 * q + 2]; }
+            }
+            a[2 * q] = h ? v.y : v.x;
+            a[2 * q + 1] = h ? v.w : v.z;
+        }
+    }
+    for (int t = tid; t < FBM; t += 256) {
+        tau[t] = (row0 + t < m) ? -INFINITY : INFINITY;  // rows past m never accept anything
+        cnt[t] = 0;
+        for (int j = 0; j < k; ++j) { list_v[j * FBM + t] = -INFINITY; list_i[j * FBM + t] = 0x7fffffff; }
+    }
+    if (tid == 0) ovf[0] = 0;
+
+    // ---- staging: thread -> (item = tid/8 + 32 q, float4 #tid%8 of the 32-wide k-chunk) ----
+    const int s_item = tid >> 3, s_k4 = tid & 7;
+    const int64_t ntiles = (n + FBN - 1) / FBN;
+    const int64_t nchunks = ntiles * NCH;
+    float4 stage[4];
+    auto g_load = [&](int64_t g) {
+        const int64_t tile = g / NCH;
+        const int c = (int)(g % NCH);
+        const int kk = 32 * c + 4 * s_k4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t item = tile * FBN + s_item + 32 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < nchunks && item < n) {
+                const float* p = B + item * ldb + kk;
+                if (kk + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                else { if (kk < K) v.x = p[0]; if (kk + 1 < K) v.y = p[1]; if (kk + 2 < K) v.z = p[2]; }
+            }
+            stage[q] = v;
+        }
+    };
+    auto s_write = [&](int slot) {
+        float* dst = Bs + slot * FBK * FLD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int item = s_item + 32 * q;
+            dst[(4 * s_k4 + 0) * FLD + item] = stage[q].x;
+            dst[(4 * s_k4 + 1) * FLD + item] = stage[q].y;
+            dst[(4 * s_k4 + 2) * FLD + item] = stage[q].z;
+            dst[(4 * s_k4 + 3) * FLD + item] = stage[q].w;
+        }
+    };
+    g_load(0); s_write(0);
+    g_load(1); s_write(1);
+    __syncthreads();
+
+    f32x16 acc[4];  // the wave's 32 users x the tile's 4 x 32 items
+    auto offer = [&](int64_t col0, int group) {
+        // group < 0: every column; otherwise only local columns [16 group, 16 group + 16)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float t = tau[row];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lc = 32 * j + l31;
+                float v = acc[j][q];
+                if (clamp) v = (v > 0.f) ? v : 0.f;
+                const bool in_group = (group < 0) || ((lc >> 4) == group);
+                if (in_group && (col0 + lc < n) && v > t) {
+                    const int pos = atomicAdd(&cnt[row], 1);
+                    if (pos < FCAP) { pend_v[pos * FBM + row] = v; pend_i[pos * FBM + row] = (int)(col0 + lc); }
+                }
+            }
+        }
+    };
+    auto merge = [&]() {  // thread t < FBM merges row t's pending candidates
+        if (tid < FBM) {
+            const int c = cnt[tid] < FCAP ? cnt[tid] : FCAP;
+            for (int p = 0; p < c; ++p) {
+                const float v = pend_v[p * FBM + tid];
+                const int ix = pend_i[p * FBM + tid];
+                int j = k - 1;
+                if (before(v, ix, list_v[j * FBM + tid], list_i[j * FBM + tid])) {
+                    while (j > 0 && before(v, ix, list_v[(j - 1) * FBM + tid], list_i[(j - 1) * FBM + tid])) {
+                        list_v[j * FBM + tid] = list_v[(j - 1) * FBM + tid];
+                        list_i[j * FBM + tid] = list_i[(j - 1) * FBM + tid];
+                        --j;
+                    }
+                    list_v[j * FBM + tid] = v;
+                    list_i[j * FBM + tid] = ix;
+                }
+            }
+            cnt[tid] = 0;
+            if (row0 + tid < m) tau[tid] = list_v[(k - 1) * FBM + tid];
+        }
+    };
+
+    int64_t g = 0;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c, ++g) {
+            g_load(g + 2);
+            const float* bs = Bs + (int)(g % 3) * FBK * FLD;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int kl = 2 * ks + h;
+                const float av = a[16 * c + ks];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bs[kl * FLD + 32 * j + l31], acc[j], 0, 0, 0);
+            }
+            s_write((int)((g + 2) % 3));
+            __syncthreads();
+        }
+        const int64_t col0 = tile * FBN;
+        offer(col0, -1);
+        __syncthreads();
+        if (tid < FBM && cnt[tid] > FCAP) ovf[0] = 1;
+        __syncthreads();
+        if (ovf[0]) {  // block-uniform: re-offer the tile in 8 groups of 16 columns
+            __syncthreads();
+            if (tid < FBM) cnt[tid] = 0;
+            if (tid == 0) ovf[0] = 0;
+            __syncthreads();
+            for (int grp = 0; grp < FBN / 16; ++grp) {
+                offer(col0, grp);
+                __syncthreads();
+                merge();
+                __syncthreads();
+            }
+        } else {
+            merge();
+            __syncthreads();
+        }
+    }
+    if (tid < FBM && row0 + tid < m) {
+        for (int j = 0; j < k; ++j) {
+            out_idx[(row0 + tid) * k + j] = list_i[j * FBM + tid];
+            if (out_val) out_val[(row0 + tid) * k + j] = list_v[j * FBM + tid];
+        }
+    }
+}
+
+template <int NCH>
+static int launch_predict_topk(const float* A, const float* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
+                               int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (3 * FBK * FLD + FBM) + sizeof(int) * (FBM + 4) + 8 * (size_t)FCAP * FBM +
+                       8 * (size_t)k * FBM;
+    static size_t allowed = 64 * 1024;
+    if (lds > allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk<NCH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return TMF_E_LAUNCH; }
+        allowed = lds;
+    }
+    const int64_t blocks = (m + FBM - 1) / FBM;
+    hipLaunchKernelGGL((k_predict_topk<NCH>), dim3((unsigned)blocks), dim3(256), lds, stream, A, B, m, n, K, lda, ldb, k,
+                       clamp, out_idx, out_val);
+    return check_launch("tmf_predict_topk_f32");
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
+                                    int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
+                                    void* stream) {
+    if (m == 0) return TMF_OK;
+    TMF_REQUIRE(A && B && out_idx && m > 0 && n > 0 && r > 0, "predict_topk: bad arguments");
+    TMF_REQUIRE(lda >= r && ldb >= r && (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) &&
+                    ((uintptr_t)B % 16 == 0), "predict_topk: operands must be 16-byte aligned with ld %% 4 == 0");
+    TMF_REQUIRE(k >= 1 && k <= n, "predict_topk: k=%d must be in [1, n=%lld]", k, (long long)n);
+    TMF_REQUIRE(n < ((int64_t)1 << 31), "predict_topk: too many items");
+    if (k > tmf::FMAXK || r > 128) {
+        tmf::set_error("predict_topk: fused kernel supports k <= %d and n_components <= 128 (got k=%d, r=%d)", tmf::FMAXK, k, r);
+        return TMF_E_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (r <= 32) return tmf::launch_predict_topk<1>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+    if (r <= 64) return tmf::launch_predict_topk<2>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+    return tmf::launch_predict_topk<4>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+}

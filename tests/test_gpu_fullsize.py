@@ -1,0 +1,127 @@
+"""Full-size (BASELINE C4: 1M users x 100K items, r=128, WMRB S=1024, ~8e7 interactions) parity through
+size-independent properties: the oracle cannot run the whole epoch in seconds, but
+  * a user's new row, its D[u, :], delta_k and loss depend only on V and the user's own data -> exact
+    oracle check on a random sample of users (fp64 closed form, step-interval criterion);
+  * an item's gradient is a weighted sum over its entry list -> fp64 re-summation on the CPU for a few
+    items, including the heaviest one (~1M entries, ~1000 segments through the slab + combine path);
+  * loss sum = sum of per-user partials; two runs are bit-identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, assert_step, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def c4():
+    sys.path.insert(0, ROOT)
+    import bench
+    from teamoflow_amd import _engine, _lib
+    from teamoflow_amd.mf.utils import random_sampler_device
+    _lib.get()
+    dev = torch.device('cuda', 0)
+    m, n, r, S, lr = 1_000_000, 100_000, 128, 1024, 0.1
+    idx, val = bench.gen_interactions(m, n, 100_000_000, 'zipf', 0, dev)
+    U0, V0 = bench.init_table(m, r, 11, dev) * 300.0, bench.init_table(n, r, 7, dev) * 100.0  # O(0.3) entries
+    plan = _engine.InteractionPlan(idx, val, m, n)
+    R = random_sampler_device(n, m, S, seed=100, device=dev)
+    wplan = _engine.WmrbPlan(plan, R)
+    st = _engine.TrainState(U0, V0, plan, r, wplan)
+    adam = _engine.adam_constants(lr)
+    loss = torch.zeros(2, dtype=torch.float64, device=dev)
+    _engine.epoch_wmrb(st, adam, n / S, loss[0:1])
+    torch.cuda.synchronize()
+    return dict(m=m, n=n, r=r, S=S, lr=lr, idx=idx, val=val, U0=U0, V0=V0, plan=plan, R=R, wplan=wplan, st=st,
+                adam=adam, loss=loss, engine=_engine)
+
+
+def test_sampled_users_match_oracle(c4):
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(0)
+    st, plan, w = c4['st'], c4['plan'], c4['wplan']
+    deg = (plan.rowptr_u[1:] - plan.rowptr_u[:-1]).cpu().numpy()
+    users = list(rng.integers(0, c4['m'], 24)) + [int(deg.argmax()), int(deg.argmin())]
+    V64 = c4['V0'].cpu().numpy().astype(np.float64)
+    rp = plan.rowptr_u.cpu().numpy()
+    for u in users:
+        b, e = rp[u], rp[u + 1]
+        idx = np.stack([np.zeros(e - b, np.int64), plan.col_u[b:e].cpu().numpy().astype(np.int64)], axis=1)
+        val = plan.val_u[b:e].cpu().numpy().astype(np.float64)
+        U64 = c4['U0'][u:u + 1].cpu().numpy().astype(np.float64)
+        Ru = c4['R'][u:u + 1].cpu().numpy().astype(np.int64)
+        t = S.wmrb_terms(U64, V64, idx, val, Ru, c4['n'], c4['S'])
+        assert rel_err(w.D[u].cpu().numpy(), t['D'][0]) < 1e-5, u
+        assert rel_err(w.delta[b:e].cpu().numpy(), t['delta']) < 1e-5, u
+        assert abs(float(st.loss_part[u]) - t['loss'].sum()) <= 1e-5 * t['loss'].sum(), u
+        gU = (t['delta'][:, None] * V64[idx[:, 1]]).sum(0) + t['D'][0] @ V64[Ru[0]]
+        assert_step(st.U_nxt[u, :c4['r']].cpu().numpy()[None], U64, gU[None], c4['lr'], what=f'user {u}')
+
+
+def test_sampled_items_match_fp64_resummation(c4):
+    st, plan, w = c4['st'], c4['plan'], c4['wplan']
+    rp = w.rowptr_e.cpu().numpy()
+    lens = np.diff(rp)
+    rng = np.random.default_rng(1)
+    items = [int(lens.argmax()), int(lens.argmin())] + list(rng.integers(0, c4['n'], 6))
+    assert lens.max() > 500_000  # the zipf head really is a ~1000-segment row
+    for j in items:
+        b, e = int(rp[j]), int(rp[j + 1])
+        rows = w.ent_row[b:e].to(torch.int64)
+        wts = w.wbuf[w.ent_w[b:e]].to(torch.float64)
+        g = (wts[:, None] * st.U[rows, :c4['r']].to(torch.float64)).sum(0).cpu().numpy()
+        assert_step(st.V_nxt[j, :c4['r']].cpu().numpy()[None], c4['V0'][j:j + 1].cpu().numpy(), g[None], c4['lr'],
+                    what=f'item {j} ({e - b} entries)')
+
+
+def test_loss_is_sum_of_user_partials_and_runs_are_bit_identical(c4):
+    st, eng = c4['st'], c4['engine']
+    total = float(c4['loss'][0])
+    assert abs(total - float(st.loss_part[:c4['m']].to(torch.float64).sum())) <= 1e-9 * total
+    U1, V1, D1 = st.U_nxt.clone(), st.V_nxt.clone(), c4['wplan'].D.clone()
+    eng.epoch_wmrb(st, c4['adam'], c4['n'] / c4['S'], c4['loss'][1:2])
+    torch.cuda.synchronize()
+    assert float(c4['loss'][1]) == total
+    assert torch.equal(U1, st.U_nxt) and torch.equal(V1, st.V_nxt) and torch.equal(D1, c4['wplan'].D)
+    # rows of users / items without any entry are untouched; pad columns stay zero
+    assert float(st.U_nxt[:, c4['r']:].abs().sum()) == 0.0 if st.ld > c4['r'] else True
+
+
+def test_full_size_mse_sampled_rows(c4):
+    """MSE epoch at the same size: sampled user rows and item rows (incl. the heaviest item) against fp64."""
+    st, plan, eng = c4['st'], c4['plan'], c4['engine']
+    loss = torch.zeros(1, dtype=torch.float64, device=st.U.device)
+    eng.epoch_mse(st, c4['adam'], loss)
+    torch.cuda.synchronize()
+    r = c4['r']
+    rng = np.random.default_rng(2)
+    rp = plan.rowptr_u.cpu().numpy()
+    tot = 0.0
+    for u in rng.integers(0, c4['m'], 16):
+        b, e = int(rp[u]), int(rp[u + 1])
+        Vr = st.V[plan.col_u[b:e].to(torch.int64), :r].to(torch.float64)
+        x = st.U[u, :r].to(torch.float64)
+        err = plan.val_u[b:e].to(torch.float64) - Vr @ x
+        g = ((-2.0 * err)[:, None] * Vr).sum(0).cpu().numpy()
+        assert_step(st.U_nxt[u, :r].cpu().numpy()[None], st.U[u, :r].cpu().numpy()[None], g[None], c4['lr'], what=f'mse user {u}')
+    rpi = plan.rowptr_i.cpu().numpy()
+    lens = np.diff(rpi)
+    for j in [int(lens.argmax())] + list(rng.integers(0, c4['n'], 5)):
+        b, e = int(rpi[j]), int(rpi[j + 1])
+        Ur = st.U[plan.row_i[b:e].to(torch.int64), :r].to(torch.float64)
+        y = st.V[j, :r].to(torch.float64)
+        err = plan.val_i[b:e].to(torch.float64) - Ur @ y
+        g = ((-2.0 * err)[:, None] * Ur).sum(0).cpu().numpy()
+        assert_step(st.V_nxt[j, :r].cpu().numpy()[None], st.V[j, :r].cpu().numpy()[None], g[None], c4['lr'], what=f'mse item {j}')
+    # loss: fp64 recomputation over ALL interactions with torch (chunked)
+    ref = 0.0
+    u_ids = plan.user_ids
+    for b in range(0, plan.nnz, 1 << 24):
+        e = min(b + (1 << 24), plan.nnz)
+        p = (st.U[u_ids[b:e], :r].to(torch.float64) * st.V[plan.col_u[b:e].to(torch.int64), :r].to(torch.float64)).sum(1)
+        ref += float(((plan.val_u[b:e].to(torch.float64) - p) ** 2).sum())
+    assert abs(float(loss[0]) - ref) <= 1e-5 * ref

@@ -229,6 +229,36 @@ def test_topk_tie_rule_and_clamp(tm):
         tm.ops.topk_stable(x, 6)
 
 
+def test_fused_predict_topk_matches_materialised_and_oracle(tm):
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(9)
+    for m, n, r in [(1, 5, 3), (100, 50, 5), (130, 257, 32), (257, 1000, 64), (300, 4099, 128), (64, 128, 100)]:
+        U = rng.standard_normal((m, r)).astype(np.float32)
+        V = rng.standard_normal((n, r)).astype(np.float32)
+        if n > 200:
+            V[50:60] = V[40]          # duplicate item rows -> exact score ties across tiles
+            V[n - 3:] = V[7]
+        Ut, Vt = torch.tensor(U), torch.tensor(V)
+        scores = tm.ops.predict_gemm(Ut, Vt)
+        for k in sorted({1, min(10, n), min(32, n)}):
+            for clamp in (False, True):
+                want = tm.ops.topk_stable(scores, k, clamp_negatives=clamp).cpu()
+                got_v, got = tm.ops.predict_topk(Ut, Vt, k, clamp_negatives=clamp, return_values=True)
+                assert torch.equal(got.cpu(), want), (m, n, r, k, clamp)
+                sc = scores.cpu().numpy()
+                ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
+                assert np.array_equal(got.cpu().numpy(), ref), (m, n, r, k, clamp)
+    # all-equal scores (everything clamped to 0): must return 0..k-1
+    Z = torch.zeros(200, 16)
+    assert tm.ops.predict_topk(Z, torch.ones(5000, 16), 10, clamp_negatives=True).cpu().tolist() == [list(range(10))] * 200
+    # scores increasing with the item index: every tile overflows the pending buffer (slow path)
+    inc = torch.arange(3000, dtype=torch.float32)[:, None] * torch.ones(1, 4)
+    got = tm.ops.predict_topk(torch.ones(7, 4), inc, 5).cpu().tolist()
+    assert got == [[2999, 2998, 2997, 2996, 2995]] * 7
+    with pytest.raises(Exception):
+        tm.ops.predict_topk(torch.ones(3, 4), torch.ones(10, 4), 33 if False else 11)
+
+
 def test_predict_gemm_shapes(tm):
     rng = np.random.default_rng(3)
     for m, n, r in [(1, 1, 1), (100, 50, 5), (129, 257, 32), (300, 1000, 128), (64, 64, 7)]:
