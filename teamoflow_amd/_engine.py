@@ -7,6 +7,7 @@ What replaces what (reference paths under /root/reference/src/teamoflow/mf/):
   epoch_wmrb  <- matrix_factorization.py:130-176 with WMRBLoss (loss_graphs.py:74-88, utils.py:94-105)
 """
 import ctypes
+import os
 
 import torch
 
@@ -22,9 +23,14 @@ def _excl_cumsum(x):
 
 
 class SegmentTable:
-    """Rows of one side cut into segments of <= chunk entries (see include/tmf.h, tmf_segments)."""
+    """Rows of one side cut into segments of <= chunk entries (see include/tmf.h, tmf_segments).
 
-    def __init__(self, rowptr, chunk=DEFAULT_CHUNK):
+    ``out_row`` (optional, int64 [rows]) maps every list row to the table row its partial sums belong
+    to (several list rows per table row: the user-chunked WMRB item lists).  Then EVERY segment gets a
+    slab slot, slots are numbered table-row-major, and all ``n_out`` table rows are finished by
+    tmf_combine_rows."""
+
+    def __init__(self, rowptr, chunk=DEFAULT_CHUNK, out_row=None, n_out=None):
         dev = rowptr.device
         rows = rowptr.numel() - 1
         lens = rowptr[1:] - rowptr[:-1]
@@ -34,10 +40,21 @@ class SegmentTable:
         ar = torch.arange(rows, device=dev)
         seg_row = torch.repeat_interleave(ar, nch, output_size=nseg)
         seg_chunk = torch.arange(nseg, device=dev) - seg_first[seg_row]
-        multi = nch > 1
-        slab_beg = _excl_cumsum(nch * multi)
-        seg_slab = torch.where(multi[seg_row], slab_beg[seg_row] + seg_chunk, torch.full_like(seg_chunk, -1))
-        long_rows = torch.nonzero(multi).flatten()
+        if out_row is None:
+            multi = nch > 1
+            slab_beg = _excl_cumsum(nch * multi)
+            seg_slab = torch.where(multi[seg_row], slab_beg[seg_row] + seg_chunk, torch.full_like(seg_chunk, -1))
+            long_rows = torch.nonzero(multi).flatten()
+            self.n_slab = int(slab_beg[-1])
+            self.long_slab_beg = torch.cat([slab_beg[long_rows], slab_beg[-1:]]).contiguous()
+        else:
+            seg_out = out_row[seg_row]
+            order = torch.sort(seg_out, stable=True)[1]  # table-row-major, list order kept inside a row
+            seg_slab = torch.empty(nseg, dtype=torch.int64, device=dev)
+            seg_slab[order] = torch.arange(nseg, device=dev)
+            long_rows = torch.arange(n_out, device=dev)
+            self.n_slab = nseg
+            self.long_slab_beg = _excl_cumsum(torch.bincount(seg_out, minlength=n_out))
         self.rows, self.chunk, self.nseg = rows, int(chunk), nseg
         self.rowptr = rowptr.contiguous()
         self.seg_row = seg_row.to(torch.int32)
@@ -45,8 +62,6 @@ class SegmentTable:
         self.seg_slab = seg_slab.to(torch.int32)
         self.long_rows = long_rows.to(torch.int32)
         self.n_long = int(long_rows.numel())
-        self.n_slab = int(slab_beg[-1])
-        self.long_slab_beg = torch.cat([slab_beg[long_rows], slab_beg[-1:]]).contiguous()
         self._c = None
 
     def cstruct(self):
@@ -85,18 +100,46 @@ class InteractionPlan:
         self.user_ids = u  # int64, CSR order (kept for the WMRB entry lists)
 
 
+def default_user_chunks(n_users, ld, target_bytes=8 << 20):
+    """Number of user blocks the WMRB item lists are cut into so that the U rows the lists of one block
+    gather (n_users / chunks * ld * 4 bytes) stay cache-resident while that block is being processed.
+    Measured at C4 (1M users, 512-byte rows, item pass ms): 1 block 100.8, 8 -> 95.9, 32 -> 81.8, 64 -> 73.2,
+    128 -> 71.1, 256 -> 71.9 (profiles/r01_user_chunk_sweep.txt)."""
+    env = os.environ.get('TMF_USER_CHUNKS')
+    if env:
+        return max(1, int(env))
+    c = -(-n_users * ld * 4 // target_bytes)
+    return int(min(max(c, 1), 128)) if c > 1 else 1
+
+
 class WmrbPlan:
     """Per-item entry lists of the WMRB item-side gradient:
     positives of the item (weight delta_k) followed by the (user, sample-slot) pairs whose static
-    negative is the item (weight D[u, s]); weights live in one buffer wbuf = [delta | D]."""
+    negative is the item (weight D[u, s]); weights live in one buffer wbuf = [delta | D].
 
-    def __init__(self, plan, R, chunk=DEFAULT_CHUNK):
+    With user_chunks = C > 1 the lists are additionally split by user block (list row = block * n_items +
+    item, blocks outermost): the waves running at any moment then gather U rows of ONE block of users,
+    which fits the Infinity Cache, instead of rows scattered over the whole table."""
+
+    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1):
         dev = R.device
         m, S = R.shape
-        nnz = plan.nnz
+        nnz, n = plan.nnz, plan.n_items
+        C = max(1, int(user_chunks))
+        upc = -(-m // C)  # users per block
         pos_k = torch.nonzero(plan.val_u > 0).flatten()  # CSR positions of the positives
         P = pos_k.numel()
-        keys = torch.cat([plan.col_u[pos_k], R.reshape(-1)])
+        pos_u = plan.user_ids[pos_k]
+        keys_pos = plan.col_u[pos_k].to(torch.int64)
+        keys_smp = R.reshape(-1).to(torch.int64)
+        if C > 1:
+            keys_pos = keys_pos + (pos_u // upc) * n
+            keys_smp = keys_smp + (torch.arange(m, device=dev) // upc).repeat_interleave(S) * n
+        counts = torch.bincount(keys_pos, minlength=C * n) + torch.bincount(keys_smp, minlength=C * n)
+        keys = torch.cat([keys_pos, keys_smp])
+        del keys_pos, keys_smp
+        if C * n < 2 ** 31:
+            keys = keys.to(torch.int32)
         order = torch.sort(keys, stable=True)[1]
         del keys
         is_pos = order < P
@@ -107,14 +150,15 @@ class WmrbPlan:
             ent_w = torch.where(is_pos, pk, nnz + e)
         else:
             ent_row, ent_w = e // S, nnz + e
-        counts = torch.bincount(plan.col_u[pos_k].to(torch.int64), minlength=plan.n_items) + \
-            torch.bincount(R.reshape(-1).to(torch.int64), minlength=plan.n_items)
-        self.S = S
-        self.R = R
+        self.S, self.R, self.user_chunks = S, R, C
         self.ent_row = ent_row.to(torch.int32).contiguous()
         self.ent_w = ent_w.to(torch.int64).contiguous()
         self.rowptr_e = _excl_cumsum(counts)
-        self.seg_e = SegmentTable(self.rowptr_e, chunk)
+        if C > 1:
+            out_row = torch.arange(C * n, device=dev) % n
+            self.seg_e = SegmentTable(self.rowptr_e, chunk, out_row=out_row, n_out=n)
+        else:
+            self.seg_e = SegmentTable(self.rowptr_e, chunk)
         self.wbuf = torch.zeros(nnz + m * S, dtype=torch.float32, device=dev)
         self.delta = self.wbuf[:nnz]
         self.D = self.wbuf[nnz:].view(m, S)

@@ -30,7 +30,8 @@ def c4():
     U0, V0 = bench.init_table(m, r, 11, dev) * 300.0, bench.init_table(n, r, 7, dev) * 100.0  # O(0.3) entries
     plan = _engine.InteractionPlan(idx, val, m, n)
     R = random_sampler_device(n, m, S, seed=100, device=dev)
-    wplan = _engine.WmrbPlan(plan, R)
+    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r)))
+    assert wplan.user_chunks > 1
     st = _engine.TrainState(U0, V0, plan, r, wplan)
     adam = _engine.adam_constants(lr)
     loss = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -64,18 +65,21 @@ def test_sampled_users_match_oracle(c4):
 
 def test_sampled_items_match_fp64_resummation(c4):
     st, plan, w = c4['st'], c4['plan'], c4['wplan']
+    n, C = c4['n'], w.user_chunks
     rp = w.rowptr_e.cpu().numpy()
-    lens = np.diff(rp)
+    lens = np.diff(rp).reshape(C, n).sum(0)  # list row = user block * n + item
     rng = np.random.default_rng(1)
-    items = [int(lens.argmax()), int(lens.argmin())] + list(rng.integers(0, c4['n'], 6))
+    items = [int(lens.argmax()), int(lens.argmin())] + list(rng.integers(0, n, 6))
     assert lens.max() > 500_000  # the zipf head really is a ~1000-segment row
     for j in items:
-        b, e = int(rp[j]), int(rp[j + 1])
-        rows = w.ent_row[b:e].to(torch.int64)
-        wts = w.wbuf[w.ent_w[b:e]].to(torch.float64)
-        g = (wts[:, None] * st.U[rows, :c4['r']].to(torch.float64)).sum(0).cpu().numpy()
+        g = np.zeros(c4['r'])
+        for blk in range(C):
+            b, e = int(rp[blk * n + j]), int(rp[blk * n + j + 1])
+            rows = w.ent_row[b:e].to(torch.int64)
+            wts = w.wbuf[w.ent_w[b:e]].to(torch.float64)
+            g += (wts[:, None] * st.U[rows, :c4['r']].to(torch.float64)).sum(0).cpu().numpy()
         assert_step(st.V_nxt[j, :c4['r']].cpu().numpy()[None], c4['V0'][j:j + 1].cpu().numpy(), g[None], c4['lr'],
-                    what=f'item {j} ({e - b} entries)')
+                    what=f'item {j} ({lens[j]} entries)')
 
 
 def test_loss_is_sum_of_user_partials_and_runs_are_bit_identical(c4):

@@ -171,6 +171,21 @@ def test_every_rank_geometry_mse_and_wmrb(tm, r):
     assert rel_err(w._state.wplan.D.cpu().numpy(), t['D']) < 1e-5
 
 
+def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
+    """TMF_USER_CHUNKS > 1: item lists split by user block, every segment through slab + combine."""
+    g = golden('wmrb_small')
+    for chunks in ('2', '7'):
+        monkeypatch.setenv('TMF_USER_CHUNKS', chunks)
+        model, _ = check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, float(g['lr']), 'wmrb',
+                                  g['R'], 100, 50, fixture=(g['U_1'], g['V_1']))
+        assert model._state.wplan.user_chunks == int(chunks)
+    monkeypatch.delenv('TMF_USER_CHUNKS')
+    base = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 3, 0.1, 'wmrb', g['R'], 100, 50)
+    monkeypatch.setenv('TMF_USER_CHUNKS', '4')
+    chunked = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 3, 0.1, 'wmrb', g['R'], 100, 50)
+    assert rel_err(chunked.loss_history_, base.loss_history_) < 1e-6
+
+
 def test_heavy_rows_are_segmented_and_combined(tm):
     """Rows longer than the segment length go through the slab + combine path."""
     rng = np.random.default_rng(7)

@@ -94,6 +94,29 @@ def test_segment_table_and_plans_against_numpy():
         assert list(ws) == list(pos_k) + list(len(v) + us * S + ss)
         assert list(rows) == list(u[pos_k]) + list(us)
     assert w.delta.numel() == len(v) and tuple(w.D.shape) == (m, S)
+    # user-chunked lists: list row = block * n + item; per item the union over blocks is the same entry set,
+    # every segment owns a slab slot and the slots of an item are consecutive
+    C = 3
+    wc = WmrbPlan(plan, torch.tensor(R), chunk=chunk, user_chunks=C)
+    upc = -(-m // C)
+    rpc = wc.rowptr_e.numpy()
+    assert len(rpc) == C * n + 1
+    for item in range(n):
+        got = []
+        for blk in range(C):
+            b, e = rpc[blk * n + item], rpc[blk * n + item + 1]
+            rows = wc.ent_row.numpy()[b:e]
+            assert ((rows // upc) == blk).all()
+            got += list(wc.ent_w.numpy()[b:e])
+        want = w.ent_w.numpy()[rpe[item]:rpe[item + 1]]
+        assert sorted(got) == sorted(want)
+    sg = wc.seg_e
+    assert sg.n_long == n and sg.n_slab == sg.nseg and (sg.seg_slab.numpy() >= 0).all()
+    assert sorted(sg.seg_slab.numpy()) == list(range(sg.nseg))
+    lb = sg.long_slab_beg.numpy()
+    item_of_seg = sg.seg_row.numpy() % n
+    for item in range(n):
+        assert sorted(sg.seg_slab.numpy()[item_of_seg == item]) == list(range(lb[item], lb[item + 1]))
 
 
 def test_reference_style_imports_and_surface():
