@@ -145,7 +145,8 @@ def main():
     wplan, R = None, None
     if args.loss == 'wmrb':
         R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
-        wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r)))
+        wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r)),
+                                 item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)))
     st = _engine.TrainState(U0, V0, plan, r, wplan)
     adam = _engine.adam_constants(args.lr)
     c = n / S

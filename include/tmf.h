@@ -106,6 +106,29 @@ int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const floa
                            float* D, float* loss_part, float* pos_part, int n_components, int epi,
                            tmf_adam adam, void* stream);
 
+/* Sliced form of the same user pass for catalogs whose V table is larger than the L2s (speed only - the
+ * results obey the same contract).  R_sorted [n_users, S] holds every user's negatives in ascending item
+ * order; slice_off [n_users, n_slices + 1] int32 gives, per user, the first sample of every item slice
+ * (slice_off[u][0] = 0, slice_off[u][n_slices] = S).  Call in this order on one stream:
+ *   tmf_wmrb_scores_f32  sp[u, s] = <U[u], V[R_sorted[u, s]]>                      (slice-major grid)
+ *   tmf_wmrb_hinge_f32   delta, D (in R_sorted order), loss_part, gpos[u] = sum_k delta_k V[j_k]
+ *   tmf_wmrb_gradu_f32   part[slice][u] = sum_{s in slice} D[u, s] V[R_sorted[u, s]]  (slice-major grid)
+ *   tmf_wmrb_finish_f32  U_out[u] = epilogue(gpos[u] + sum_slice part[slice][u])
+ * sp [n_users, S], gpos [n_users, ld], part [n_slices * n_users, ld] are caller-provided scratch. */
+int tmf_wmrb_scores_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                        int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
+                        int n_components, void* stream);
+int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
+                       int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
+                       float* gpos, float* delta, float* D, float* loss_part, int n_components,
+                       void* stream);
+int tmf_wmrb_gradu_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                       int32_t n_users, int32_t S, const float* D, const float* V, float* part,
+                       int n_components, void* stream);
+int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
+                        const float* U_old, float* U_out, int n_components, int epi, tmf_adam adam,
+                        void* stream);
+
 /* K6 standalone: W[rows] = fresh-Adam(W[rows], G[rows]) in place over n_rows x ld floats. */
 int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,
                             tmf_adam adam, void* stream);

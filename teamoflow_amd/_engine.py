@@ -112,6 +112,19 @@ def default_user_chunks(n_users, ld, target_bytes=8 << 20):
     return int(min(max(c, 1), 128)) if c > 1 else 1
 
 
+def default_item_slices(n_items, ld):
+    """Number of item slices of the SLICED WMRB user pass; 1 = the fused single-kernel pass (default).
+
+    The sliced pass (tmf_wmrb_scores/hinge/gradu/finish) keeps every user's negatives sorted by item and
+    walks the catalog in ~4 MB slices so that V rows are gathered from the XCD L2s instead of the Infinity
+    Cache.  Measured at C4 (profiles/r01_sliced_user_pass.txt): the gathers do get faster (scores 46 ms =
+    11.7 TB/s, gradU 56 ms = 9.6 TB/s, against ~8 TB/s fused) but the hinge arithmetic, which the fused
+    kernel hides behind other workgroups' gathers, becomes a 40 ms kernel of its own: 143 ms against 140 ms
+    fused.  It therefore stays opt-in (TMF_ITEM_SLICES=n) until the hinge work is overlapped in-launch."""
+    env = os.environ.get('TMF_ITEM_SLICES')
+    return max(1, int(env)) if env else 1
+
+
 class WmrbPlan:
     """Per-item entry lists of the WMRB item-side gradient:
     positives of the item (weight delta_k) followed by the (user, sample-slot) pairs whose static
@@ -121,9 +134,21 @@ class WmrbPlan:
     item, blocks outermost): the waves running at any moment then gather U rows of ONE block of users,
     which fits the Infinity Cache, instead of rows scattered over the whole table."""
 
-    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1):
+    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1):
         dev = R.device
         m, S = R.shape
+        self.n_slices = max(1, int(item_slices))
+        self.sample_perm = None
+        if self.n_slices > 1:
+            # every user's negatives in ascending item order (the order of s is immaterial to the loss);
+            # D is then produced in this order too - D_in_model_order() maps it back
+            R64, self.sample_perm = torch.sort(R.to(torch.int64), dim=1, stable=True)
+            R = R64.to(torch.int32).contiguous()
+            width = -(-plan.n_items // self.n_slices)
+            bnd = torch.arange(self.n_slices + 1, device=dev, dtype=torch.int64) * width
+            self.slice_off = torch.searchsorted(R64, bnd[None, :].expand(m, -1).contiguous()).to(torch.int32).contiguous()
+            self.slice_off[:, -1] = S
+            del R64
         nnz, n = plan.nnz, plan.n_items
         C = max(1, int(user_chunks))
         upc = -(-m // C)  # users per block
@@ -163,6 +188,14 @@ class WmrbPlan:
         self.delta = self.wbuf[:nnz]
         self.D = self.wbuf[nnz:].view(m, S)
 
+    def D_in_model_order(self):
+        """D[u, s] indexed like the model's random_ind (the sliced pass keeps samples sorted by item)."""
+        if self.sample_perm is None:
+            return self.D
+        out = torch.empty_like(self.D)
+        out.scatter_(1, self.sample_perm, self.D)
+        return out
+
 
 class TrainState:
     """Double-buffered factor tables [rows, ld] and the scratch the passes need."""
@@ -176,10 +209,16 @@ class TrainState:
         self.U_nxt = torch.empty_like(self.U)
         self.V_nxt = torch.empty_like(self.V)
         self.plan, self.wplan = plan, wplan
+        self.side_streams = None
         n_slab = max(plan.seg_u.n_slab, plan.seg_i.n_slab, wplan.seg_e.n_slab if wplan else 0, 1)
         self.slab = torch.empty(n_slab, self.ld, dtype=torch.float32, device=dev)
         n_part = max(plan.seg_u.nseg, plan.n_users, 1)
         self.loss_part = torch.zeros(n_part, dtype=torch.float32, device=dev)
+        if wplan is not None and wplan.n_slices > 1:
+            m, S = wplan.R.shape
+            self.sp = torch.empty(m, S, dtype=torch.float32, device=dev)
+            self.gpos = torch.empty(m, self.ld, dtype=torch.float32, device=dev)
+            self.part = torch.empty(wplan.n_slices * m, self.ld, dtype=torch.float32, device=dev)
 
     def _pad(self, W, dev):
         W = torch.as_tensor(W).detach().to(device=dev, dtype=torch.float32)
@@ -245,16 +284,59 @@ def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=No
     _row_pass_finish(lib, p.seg_i, st.slab, st.V, V_out, r, item_epi, adam, s)
 
 
+def _wmrb_user_pass_sliced(lib, st, adam, c):
+    """scores -> hinge -> gradU -> finish over batches of users, alternating between two side streams so
+    that the VALU-bound hinge kernel of one batch runs beside the memory-bound slice kernels of the next
+    (in the fused kernel that overlap happens between workgroups of one launch)."""
+    p, w, r, ld = st.plan, st.wplan, st.r, st.ld
+    i32 = ctypes.c_int32
+    m, S, ns = p.n_users, w.S, w.n_slices
+    nb = max(1, min(int(os.environ.get('TMF_USER_BATCHES', '4')), m))
+    bounds = [m * b // nb for b in range(nb + 1)]
+    main = torch.cuda.current_stream()
+    if st.side_streams is None:
+        st.side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = st.side_streams if nb > 1 else [main]
+    for sd in streams:
+        if sd is not main:
+            sd.wait_stream(main)
+
+    def at(t, row):  # device pointer of row `row` of a 2-D tensor (or element of a 1-D one)
+        return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
+
+    for b in range(nb):
+        b0, n_b = bounds[b], bounds[b + 1] - bounds[b]
+        if n_b == 0:
+            continue
+        with torch.cuda.stream(streams[b % len(streams)]):
+            sp = _lib.stream_ptr()
+            _lib.check(lib.tmf_wmrb_scores_f32(at(w.R, b0), at(w.slice_off, b0), i32(ns), i32(n_b), i32(S), at(st.U, b0),
+                                               _lib.ptr(st.V), at(st.sp, b0), r, sp), lib)
+            _lib.check(lib.tmf_wmrb_hinge_f32(at(p.rowptr_u, b0), _lib.ptr(p.col_u), _lib.ptr(p.val_u), at(st.sp, b0),
+                                              i32(n_b), i32(S), c, at(st.U, b0), _lib.ptr(st.V), at(st.gpos, b0),
+                                              _lib.ptr(w.delta), at(w.D, b0), at(st.loss_part, b0), r, sp), lib)
+            _lib.check(lib.tmf_wmrb_gradu_f32(at(w.R, b0), at(w.slice_off, b0), i32(ns), i32(n_b), i32(S), at(w.D, b0),
+                                              _lib.ptr(st.V), at(st.part, ns * b0), r, sp), lib)
+            _lib.check(lib.tmf_wmrb_finish_f32(at(st.gpos, b0), at(st.part, ns * b0), i32(ns), i32(n_b), at(st.U, b0),
+                                               at(st.U_nxt, b0), r, _lib.EPI_ADAM, adam, sp), lib)
+    for sd in streams:
+        if sd is not main:
+            main.wait_stream(sd)
+
+
 def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):
     """One WMRB epoch.  loss_out receives sum over positives of log(1 + M_k)."""
     lib, p, w, r = _lib.get(), st.plan, st.wplan, st.r
     s = _lib.stream_ptr()
     if prof:
         prof.start('wmrb_user_pass')
-    _lib.check(lib.tmf_wmrb_user_pass_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
-                                          p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
-                                          _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None, r,
-                                          _lib.EPI_ADAM, adam, s), lib)
+    if w.n_slices > 1:
+        _wmrb_user_pass_sliced(lib, st, adam, c)
+    else:
+        _lib.check(lib.tmf_wmrb_user_pass_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
+                                              p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
+                                              _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None, r,
+                                              _lib.EPI_ADAM, adam, s), lib)
     if prof:
         prof.stop('wmrb_user_pass')
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)

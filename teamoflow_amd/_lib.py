@@ -48,6 +48,10 @@ SIGNATURES = {
     'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P,
                                      _I, _I, Adam, _P]),
+    'tmf_wmrb_scores_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
+    'tmf_wmrb_hinge_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'tmf_wmrb_gradu_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
+    'tmf_wmrb_finish_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _I, _I, Adam, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
     'tmf_sum_f32': (_I, [_P, _L, _P, _P]),
     'tmf_gather_rows_cols_f32': (_I, [_P, _P, _P, _L, _L, _L, _P]),

@@ -20,10 +20,13 @@ constexpr int kUnrollW = 4;
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
-template <int G, int NV>
+// SLICED = true is the middle kernel of the sliced user pass (see k_wmrb_slice below): sp[u, :] comes from
+// global memory (sp_in) instead of phase 1, phase 3 is skipped, and the caller asks for the gradient
+// epilogue so that U_out receives only the positives' part  sum_k delta_k V[j_k].
+template <int G, int NV, bool SLICED>
 __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int32_t* __restrict__ R, int S, float c, const float* __restrict__ U_old,
+    const int32_t* __restrict__ R, const float* __restrict__ sp_in, int S, float c, const float* __restrict__ U_old,
     const float* __restrict__ V_old, float* __restrict__ U_out, float* __restrict__ delta,
     float* __restrict__ Dg, float* __restrict__ loss_part, float* __restrict__ pos_part, int epi,
     tmf_adam adam) {
@@ -61,6 +64,9 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
         Frag<NV> x;
         load_row<G, NV>(x, U_old, u, g);
         // ---- phase 1 ----
+        if (SLICED) {
+            for (int s = tid; s < S; s += kThreads) sp[s] = sp_in[u * (int64_t)S + s];
+        } else
         for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
             Frag<NV> y[kUnrollW];
 #pragma unroll
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
             __syncthreads();
         }
         // ---- phase 3 ----
+        if (!SLICED)
         for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
             Frag<NV> y[kUnrollW];
             float d[kUnrollW];
@@ -221,9 +228,9 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     }
 }
 
-template <int G, int NV>
+template <int G, int NV, bool SLICED>
 static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
-                            int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
+                            const float* sp_in, int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
                             float* U_out, float* delta, float* D, float* loss_part, float* pos_part, int epi,
                             tmf_adam adam, hipStream_t stream) {
     const size_t lds = sizeof(float) * ((size_t)2 * round4(S) + 3 * kPosChunk + (size_t)kWaves * 4 * G * NV + 2 * kWaves);
@@ -233,7 +240,7 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
     }
     static size_t allowed = 64 * 1024;  // per template instance
     if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, SLICED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
@@ -241,9 +248,84 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
         }
         allowed = lds;
     }
-    hipLaunchKernelGGL((k_wmrb_user<G, NV>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col, val,
-                       R, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
-    return check_launch("tmf_wmrb_user_pass_f32");
+    hipLaunchKernelGGL((k_wmrb_user<G, NV, SLICED>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
+                       val, R, sp_in, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
+    return check_launch(SLICED ? "tmf_wmrb_hinge_f32" : "tmf_wmrb_user_pass_f32");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sliced user pass.  The fused kernel above gathers V rows over the whole item table (51 MB at
+// 100K x 128: served by the Infinity Cache at ~8 TB/s).  Here the S negatives of every user are kept
+// sorted by item id and the catalog is cut into slices of ~2-4 MB of V rows; blocks are numbered
+// slice-major, so the workgroups resident at any moment gather from ONE slice, which the XCD L2s hold
+// (13-14 TB/s measured for the same gather, profiles/r01_user_chunk_sweep.txt).  Three kernels:
+//   k_wmrb_slice<SCORES>  sp[u, s]  = <U[u], V[R[u, s]]>            for s in the slice      -> global
+//   k_wmrb_user<SLICED>   hinge math on sp (+ positives): delta, D, loss, gpos[u] = sum_k delta_k V[j_k]
+//   k_wmrb_slice<GRADU>   part[slice][u] = sum_{s in slice} D[u, s] V[R[u, s]]              -> global
+//   k_wmrb_finish         gU[u] = gpos[u] + sum_slice part[slice][u] (fixed order) -> epilogue
+// Block placement is used for speed only; any dispatch order gives the same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSliceUsers = 128;  // users per workgroup of k_wmrb_slice
+
+template <int G, int NV, bool GRADU>
+__global__ __launch_bounds__(kThreads) void k_wmrb_slice(
+    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
+    int64_t n_groups, const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ sp,
+    const float* __restrict__ D, float* __restrict__ part) {
+    constexpr int NG = 64 / G, NGB = NG * kWaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane & (G - 1), gid = wave * NG + lane / G;
+    const int64_t sl = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    const int64_t ubeg = grp * kSliceUsers;
+    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
+    for (int64_t u = ubeg + gid; u < uend; u += NGB) {
+        const int beg = off[u * (n_slices + 1) + sl], end = off[u * (n_slices + 1) + sl + 1];
+        const int32_t* Ru = R + u * (int64_t)S;
+        Frag<NV> x, acc;
+        if (GRADU) zero<NV>(acc);
+        else load_row<G, NV>(x, U, u, g);
+        for (int s0 = beg; s0 < end; s0 += kUnrollW) {
+            Frag<NV> y[kUnrollW];
+            float d[kUnrollW];
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) {
+                const int s = s0 + t;
+                d[t] = 0.f;
+                bool want = s < end;
+                if (GRADU && want) { d[t] = D[u * (int64_t)S + s]; want = d[t] != 0.f; }
+                if (want) load_row<G, NV>(y[t], V, Ru[s], g);
+                else zero<NV>(y[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) {
+                if (GRADU) {
+                    axpy<NV>(acc, d[t], y[t]);
+                } else {
+                    const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
+                    if (g == 0 && s0 + t < end) sp[u * (int64_t)S + s0 + t] = p;
+                }
+            }
+        }
+        if (GRADU) store_row<G, NV>(acc, part, sl * n_users + u, g);
+    }
+}
+
+template <int G, int NV>
+__global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* __restrict__ gpos, const float* __restrict__ part,
+                                                          int n_slices, int64_t n_users, const float* __restrict__ U_old,
+                                                          float* __restrict__ U_out, int epi, tmf_adam adam) {
+    constexpr int NG = 64 / G, NGB = NG * kWaves;
+    const int lane = threadIdx.x & 63, g = lane & (G - 1);
+    const int64_t u = (int64_t)blockIdx.x * NGB + (threadIdx.x >> 6) * NG + lane / G;
+    if (u >= n_users) return;
+    Frag<NV> acc;
+    load_row<G, NV>(acc, gpos, u, g);
+    for (int sl = 0; sl < n_slices; ++sl) {
+        Frag<NV> y;
+        load_row<G, NV>(y, part, sl * n_users + u, g);
+        add<NV>(acc, y);
+    }
+    row_epilogue<G, NV>(acc, U_old, U_out, u, g, epi, adam);
 }
 
 }  // namespace tmf
@@ -261,9 +343,78 @@ extern "C" int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col,
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_user_pass: bad epilogue %d", epi);
     const RowGeom geom = row_geom(n_components);
 #define CALL(G_, NV_)                                                                                           \
-    return launch_wmrb_user<G_, NV_>(rowptr, col, val, R, n_users, S, c, U_old, V_old, U_out, delta, D, loss_part, \
-                                     pos_part, epi, adam, (hipStream_t)stream)
+    return launch_wmrb_user<G_, NV_, false>(rowptr, col, val, R, nullptr, n_users, S, c, U_old, V_old, U_out, delta, D, \
+                                            loss_part, pos_part, epi, adam, (hipStream_t)stream)
     TMF_DISPATCH_GEOM(geom, CALL);
 #undef CALL
     return TMF_OK;
+}
+
+extern "C" int tmf_wmrb_scores_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                                   int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
+                                   int n_components, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(R_sorted && slice_off && U && V && sp && n_slices > 0 && S > 0, "wmrb_scores: bad arguments");
+    const RowGeom geom = row_geom(n_components);
+    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
+    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_scores: grid too large");
+#define CALL(G_, NV_)                                                                                               \
+    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, false>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,       \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, U, V, sp, \
+                       (const float*)nullptr, (float*)nullptr)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_scores_f32");
+}
+
+extern "C" int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
+                                  int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
+                                  float* gpos, float* delta, float* D, float* loss_part, int n_components,
+                                  void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(rowptr && sp && U_old && V_old && gpos && D && n_users > 0 && S > 0, "wmrb_hinge: bad arguments");
+    const RowGeom geom = row_geom(n_components);
+    tmf_adam none = {0.f, 0.f, 0.f, 0.f};
+#define CALL(G_, NV_)                                                                                                  \
+    return launch_wmrb_user<G_, NV_, true>(rowptr, col, val, nullptr, sp, n_users, S, c, U_old, V_old, gpos, delta, D, \
+                                           loss_part, nullptr, TMF_EPI_GRAD, none, (hipStream_t)stream)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return TMF_OK;
+}
+
+extern "C" int tmf_wmrb_gradu_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                                  int32_t n_users, int32_t S, const float* D, const float* V, float* part,
+                                  int n_components, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(R_sorted && slice_off && D && V && part && n_slices > 0 && S > 0, "wmrb_gradu: bad arguments");
+    const RowGeom geom = row_geom(n_components);
+    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
+    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_gradu: grid too large");
+#define CALL(G_, NV_)                                                                                              \
+    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, true>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,       \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,     \
+                       (const float*)nullptr, V, (float*)nullptr, D, part)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_gradu_f32");
+}
+
+extern "C" int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
+                                   const float* U_old, float* U_out, int n_components, int epi, tmf_adam adam,
+                                   void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(gpos && part && U_out && n_slices > 0 && (epi == TMF_EPI_GRAD || U_old), "wmrb_finish: bad arguments");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_finish: bad epilogue %d", epi);
+    const RowGeom geom = row_geom(n_components);
+#define CALL(G_, NV_)                                                                                             \
+    {                                                                                                             \
+        constexpr int per_block = (64 / G_) * kWaves;                                                             \
+        hipLaunchKernelGGL((k_wmrb_finish<G_, NV_>), dim3((unsigned)(((int64_t)n_users + per_block - 1) / per_block)), \
+                           dim3(kThreads), 0, (hipStream_t)stream, gpos, part, (int)n_slices, (int64_t)n_users, U_old, \
+                           U_out, epi, adam);                                                                     \
+    }
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_finish_f32");
 }

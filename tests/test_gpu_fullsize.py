@@ -30,14 +30,17 @@ def c4():
     U0, V0 = bench.init_table(m, r, 11, dev) * 300.0, bench.init_table(n, r, 7, dev) * 100.0  # O(0.3) entries
     plan = _engine.InteractionPlan(idx, val, m, n)
     R = random_sampler_device(n, m, S, seed=100, device=dev)
-    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r)))
+    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r)),
+                             item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)))
     assert wplan.user_chunks > 1
+    Dm = None
     st = _engine.TrainState(U0, V0, plan, r, wplan)
     adam = _engine.adam_constants(lr)
     loss = torch.zeros(2, dtype=torch.float64, device=dev)
     _engine.epoch_wmrb(st, adam, n / S, loss[0:1])
     torch.cuda.synchronize()
     return dict(m=m, n=n, r=r, S=S, lr=lr, idx=idx, val=val, U0=U0, V0=V0, plan=plan, R=R, wplan=wplan, st=st,
+                D_model=wplan.D_in_model_order(),
                 adam=adam, loss=loss, engine=_engine)
 
 
@@ -56,7 +59,7 @@ def test_sampled_users_match_oracle(c4):
         U64 = c4['U0'][u:u + 1].cpu().numpy().astype(np.float64)
         Ru = c4['R'][u:u + 1].cpu().numpy().astype(np.int64)
         t = S.wmrb_terms(U64, V64, idx, val, Ru, c4['n'], c4['S'])
-        assert rel_err(w.D[u].cpu().numpy(), t['D'][0]) < 1e-5, u
+        assert rel_err(c4['D_model'][u].cpu().numpy(), t['D'][0]) < 1e-5, u
         assert rel_err(w.delta[b:e].cpu().numpy(), t['delta']) < 1e-5, u
         assert abs(float(st.loss_part[u]) - t['loss'].sum()) <= 1e-5 * t['loss'].sum(), u
         gU = (t['delta'][:, None] * V64[idx[:, 1]]).sum(0) + t['D'][0] @ V64[Ru[0]]

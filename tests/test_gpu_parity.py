@@ -140,7 +140,7 @@ def test_wmrb_fixtures(tm, golden, name):
     check_one_step(tm, g[f'U_{E}'], g[f'V_{E}'], g['indices'], g['values'], g['A'].shape, lr, 'wmrb', g['R'], n_items, n_samples)
     if name == 'wmrb_small':
         st = one._state
-        assert rel_err(st.wplan.D.cpu().numpy(), g['D_first']) < 1e-5
+        assert rel_err(st.wplan.D_in_model_order().cpu().numpy(), g['D_first']) < 1e-5
         pos = g['values'] > 0
         assert rel_err(st.wplan.delta.cpu().numpy()[pos], g['delta_first']) < 1e-5
 
@@ -168,7 +168,7 @@ def test_every_rank_geometry_mse_and_wmrb(tm, r):
     lr = 0.01
     check_one_step(tm, U0, V0, idx, val, (m, n), lr)
     w, t = check_one_step(tm, U0, V0, idx, val, (m, n), lr, 'wmrb', R, n, S_)
-    assert rel_err(w._state.wplan.D.cpu().numpy(), t['D']) < 1e-5
+    assert rel_err(w._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
 
 
 def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
@@ -184,6 +184,30 @@ def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
     monkeypatch.setenv('TMF_USER_CHUNKS', '4')
     chunked = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 3, 0.1, 'wmrb', g['R'], 100, 50)
     assert rel_err(chunked.loss_history_, base.loss_history_) < 1e-6
+
+
+@pytest.mark.parametrize('slices', ['2', '5', '64'])
+def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices):
+    """TMF_ITEM_SLICES > 1: scores / hinge / gradU / finish kernels instead of the fused user pass."""
+    monkeypatch.setenv('TMF_ITEM_SLICES', slices)
+    for name in ('wmrb_small', 'wmrb_mixed'):
+        g = golden(name)
+        model, t = check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, float(g['lr']), 'wmrb',
+                                  g['R'], int(g['n_items']), int(g['n_samples']), fixture=(g['U_1'], g['V_1']))
+        assert model._state.wplan.n_slices == int(slices)
+        assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
+    g = golden('wmrb_small')
+    sliced = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 25, 0.1, 'wmrb', g['R'], 100, 50)
+    assert rel_err(sliced.loss_history_[:3], g['loss'][:3]) < 1e-5 and rel_err(sliced.loss_history_, g['loss']) < 2e-3
+    monkeypatch.setenv('TMF_USER_CHUNKS', '3')
+    rng = np.random.default_rng(int(slices))
+    m, n, r, S_ = 41, 67, 100, 23
+    A = (rng.random((m, n)) < 0.15) * rng.integers(-1, 6, (m, n))
+    idx, val = np.argwhere(A != 0), A[A != 0].astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
+    check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
 
 
 def test_heavy_rows_are_segmented_and_combined(tm):
