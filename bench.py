@@ -106,6 +106,91 @@ def recall_parity(dev):
     return got, want
 
 
+PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_c4_latest.json')
+PMC_KERNELS = {'wmrb_user_pass': 'tmf::k_wmrb_user<32, 1, false>', 'wmrb_item_pass': 'tmf::k_wsum_pass<32, 1>',
+               'mse_item_pass': 'tmf::k_mse_pass<32, 1>', 'mse_user_pass': 'tmf::k_mse_pass<32, 1>'}
+
+
+def pmc_traffic(kname):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
+    command (FETCH_SIZE and WRITE_SIZE in separate runs, bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, the
+    gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect counters itself; the workload is
+    seeded, so the profile applies to this run.  None when no profile is committed."""
+    try:
+        d = json.load(open(PMC_FILE))
+        return float(d[PMC_KERNELS[kname]]['hbm_traffic_bytes_per_launch_corrected']), os.path.relpath(PMC_FILE, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box
+    shows all 256 host CPUs but grants a 16-core share; spinning up 256 OpenMP threads there stalls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, 16) if n > 64 else n
+
+
+def small_configs(dev):
+    """BASELINE configs 1-3 (CPU-runnable shapes): fit() wall time on the GPU (hipGraph-replayed epochs)
+    next to the dense-faithful CPU restatement of the reference formulation (oracle/dense_ref.py: identity
+    feature matmuls, [m, n] scores, autograd, fresh Adam) timed over the same region the reference times."""
+    from oracle import datagen as G
+    from oracle import dense_ref
+    from teamoflow_amd.mf.initializer_graphs import FixedInitializer
+    from teamoflow_amd.mf.loss_graphs import WMRBLoss
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    from teamoflow_amd.mf.sparse import SparseInteractions, eye
+    out = {}
+    cases = [('C1', 100, 50, 5, 0.05, 'mse', 1e-2, 450, 450, None),
+             ('C2', 943, 1682, 32, 100000 / (0.9 * 943 * 1682), 'mse', 1e-3, 100, 100, None),
+             ('C3', 6040, 3706, 64, 1000209 / (0.9 * 6040 * 3706), 'wmrb', 0.1, 100, 2, 3706 // 2)]
+    for name, m, n, r, density, loss, lr, epochs, cpu_epochs, S in cases:
+        np.random.seed(0)
+        idx, val, shape, A = G.generate_random_interaction(m, n, density=density)
+        U0 = G.normal_init(m, r, 1) if loss == 'mse' else G.uniform_init(m, r, 1)
+        V0 = G.normal_init(n, r, 2) if loss == 'mse' else G.uniform_init(n, r, 2)
+        kw = dict(user_weight_graph=FixedInitializer(U0), item_weight_graph=FixedInitializer(V0))
+        R = None
+        if loss == 'wmrb':
+            R = np.stack([np.random.choice(n, S, replace=False) for _ in range(m)])
+            kw.update(loss_graph=WMRBLoss(), n_users=m, n_items=n, n_samples=S)
+        model = MatrixFactorization(r, **kw)
+        model.verbose = False
+        if R is not None:
+            model.random_ind = torch.as_tensor(R)
+        inter = SparseInteractions(idx, val, shape)
+        model.fit(epochs, eye(m), eye(n), inter, lr=lr)      # includes graph capture
+        first = model.fit_seconds_
+        model.fit(epochs, eye(m), eye(n), inter, lr=lr)
+        gpu_s = model.fit_seconds_
+        torch.set_num_threads(host_cores())
+        ref = dense_ref.fit_dense(U0, V0, idx, val, loss, cpu_epochs, lr, random_ind=R, n_items=n, n_samples=S)
+        cpu_per_epoch = ref['seconds'] / cpu_epochs
+        k = min(len(ref['loss']), len(model.loss_history_))
+        out[name] = dict(shape=[m, n], r=r, loss=loss, nnz=int(len(val)), epochs=epochs,
+                         gpu_fit_seconds=gpu_s, gpu_fit_seconds_first_call=first,
+                         gpu_interactions_per_sec=len(val) * epochs / gpu_s,
+                         cpu_dense_seconds_per_epoch=cpu_per_epoch, cpu_epochs_timed=cpu_epochs,
+                         cpu_interactions_per_sec=len(val) / cpu_per_epoch, cpu_threads=torch.get_num_threads(),
+                         loss_rel_diff_first_epochs=float(np.abs(np.array(model.loss_history_[:k]) - ref['loss'][:k]).max()
+                                                          / np.abs(ref['loss'][:k]).max()),
+                         recall_at_10=float(model.recall_at_k(torch.tensor(A)).mean()))
+        log(f'[bench] {name}: {out[name]}')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,6 +204,7 @@ def main():
     ap.add_argument('--loss', choices=['wmrb', 'mse'], default='wmrb')
     ap.add_argument('--item-dist', choices=['zipf', 'uniform'], default='zipf')
     ap.add_argument('--lr', type=float, default=0.1)
+    ap.add_argument('--small-configs', action='store_true', help='also time BASELINE configs 1-3 (GPU fit vs dense CPU restatement)')
     ap.add_argument('--no-extras', action='store_true', help='skip cpu baseline / predict / mse side measurements')
     args = ap.parse_args()
 
@@ -209,8 +295,10 @@ def main():
         kms = prof.mean_ms('mse_item_pass')
         other = {'mse_user_pass_ms': prof.mean_ms('mse_user_pass'), 'mse_user_pass_alg_bytes': ub}
     achieved = kbytes / (kms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(kname)
     roofline = dict(bound='hbm', kernel=kname, achieved=achieved, peak=HBM_PEAK / 1e9, unit='GB/s',
-                    frac=achieved / (HBM_PEAK / 1e9), traffic=None, kernel_ms=kms, alg_bytes_per_launch=kbytes,
+                    frac=achieved / (HBM_PEAK / 1e9), traffic=traffic, traffic_source=traffic_src, kernel_ms=kms,
+                    alg_bytes_per_launch=kbytes,
                     epoch_alg_bytes=ub + ib, epoch_frac=(ub + ib) / (ms_per_step * 1e-3) / HBM_PEAK, **other)
 
     out = dict(metric='train_interactions_per_sec', value=nnz_total / (elapsed / args.steps), unit='interactions/s',
@@ -242,6 +330,8 @@ def main():
                                f'(tmf_predict_topk_f32); fp32 MFMA peak 157.3 TF')
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want), case='C1 golden fixture')
+    if rank == 0 and world == 1 and args.small_configs:
+        out['small_configs'] = small_configs(dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

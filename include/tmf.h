@@ -103,8 +103,11 @@ int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int6
 int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                            const int32_t* R, int32_t n_users, int32_t S, float c,
                            const float* U_old, const float* V_old, float* U_out, float* delta,
-                           float* D, float* loss_part, float* pos_part, int n_components, int epi,
-                           tmf_adam adam, void* stream);
+                           float* D, float* loss_part, float* pos_part, float* workspace,
+                           int n_components, int epi, tmf_adam adam, void* stream);
+/* Bytes of `workspace` the call above needs: 0 while the per-user scores fit the 160 KB of LDS
+ * (n_samples up to ~19K), otherwise n_users * round4(S) floats kept in global memory. */
+size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int n_components);
 
 /* Sliced form of the same user pass for catalogs whose V table is larger than the L2s (speed only - the
  * results obey the same contract).  R_sorted [n_users, S] holds every user's negatives in ascending item

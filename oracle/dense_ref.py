@@ -232,3 +232,27 @@ def dcg_at_k_dense(user_embedding, item_embedding, A, k=10, ideal=False):
         numerator, _ = tf_top_k(numerator, n)
     denom = torch.log1p(torch.arange(1, n + 1, dtype=p.dtype)) / np.log(np.float32(2.0))
     return (numerator / denom[None, :])[:, :k].sum(dim=1).numpy()
+
+
+def ndcg_at_k_dense(user_embedding, item_embedding, A, k=10, preserve_rows=False):
+    """matrix_factorization.py:397-413."""
+    dcg = dcg_at_k_dense(user_embedding, item_embedding, A, k)
+    idcg = dcg_at_k_dense(user_embedding, item_embedding, A, k, ideal=True)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        ndcg = dcg / idcg
+    if not preserve_rows:
+        return ndcg[np.count_nonzero(np.asarray(A), axis=1) > 0]
+    return np.where(~np.isnan(ndcg), ndcg, 0.0).astype(np.float32)
+
+
+def f1_at_k_dense(user_embedding, item_embedding, A, k=10, beta=1.0):
+    """matrix_factorization.py:314-318 (denominator beta^2 (p + r), as the reference has it)."""
+    prec = precision_at_k_dense(user_embedding, item_embedding, A, k).mean()
+    rec = recall_at_k_dense(user_embedding, item_embedding, A, k).mean()
+    return ((1 + beta ** 2) * prec * rec) / (beta ** 2 * (prec + rec))
+
+
+def predict_ranks_dense(user_embedding, item_embedding, A):
+    """matrix_factorization.py:209-216: global descending ranking of the unobserved predictions."""
+    _, unobserved = predict_dense(user_embedding, item_embedding, A)
+    return tf_top_k(torch.as_tensor(unobserved), len(unobserved))[1].numpy()

@@ -214,6 +214,11 @@ class TrainState:
         self.slab = torch.empty(n_slab, self.ld, dtype=torch.float32, device=dev)
         n_part = max(plan.seg_u.nseg, plan.n_users, 1)
         self.loss_part = torch.zeros(n_part, dtype=torch.float32, device=dev)
+        self.user_ws = None
+        if wplan is not None:
+            ws = _lib.load_library().tmf_wmrb_user_workspace_bytes(plan.n_users, wplan.S, self.r)
+            if ws:
+                self.user_ws = torch.empty(ws // 4, dtype=torch.float32, device=dev)
         if wplan is not None and wplan.n_slices > 1:
             m, S = wplan.R.shape
             self.sp = torch.empty(m, S, dtype=torch.float32, device=dev)
@@ -335,8 +340,8 @@ def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, pro
     else:
         _lib.check(lib.tmf_wmrb_user_pass_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
                                               p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
-                                              _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None, r,
-                                              _lib.EPI_ADAM, adam, s), lib)
+                                              _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None,
+                                              _lib.ptr(st.user_ws), r, _lib.EPI_ADAM, adam, s), lib)
     if prof:
         prof.stop('wmrb_user_pass')
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)

@@ -46,8 +46,9 @@ SIGNATURES = {
     'tmf_mse_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
-    'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P,
+    'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _I, _I, Adam, _P]),
+    'tmf_wmrb_user_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, _I]),
     'tmf_wmrb_scores_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
     'tmf_wmrb_hinge_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_gradu_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),

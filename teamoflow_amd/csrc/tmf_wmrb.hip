@@ -23,10 +23,13 @@ __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 // SLICED = true is the middle kernel of the sliced user pass (see k_wmrb_slice below): sp[u, :] comes from
 // global memory (sp_in) instead of phase 1, phase 3 is skipped, and the caller asks for the gradient
 // epilogue so that U_out receives only the positives' part  sum_k delta_k V[j_k].
-template <int G, int NV, bool SLICED>
+// BIG = true: n_samples too large for LDS - sp[u, :] and D[u, :] live in global memory (sp_ws row of
+// round4(S) floats per user, D's own row); same arithmetic, only the storage changes.
+template <int G, int NV, bool SLICED, bool BIG>
 __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int32_t* __restrict__ R, const float* __restrict__ sp_in, int S, float c, const float* __restrict__ U_old,
+    const int32_t* __restrict__ R, const float* __restrict__ sp_in, float* __restrict__ sp_ws, int S, float c,
+    const float* __restrict__ U_old,
     const float* __restrict__ V_old, float* __restrict__ U_out, float* __restrict__ delta,
     float* __restrict__ Dg, float* __restrict__ loss_part, float* __restrict__ pos_part, int epi,
     tmf_adam adam) {
@@ -35,16 +38,16 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     constexpr int LD = 4 * G * NV;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int S4 = round4(S);
-    float* sp = reinterpret_cast<float*>(smem_raw);   // [S4]   sampled scores (tail = -inf)
-    float* Dl = sp + S4;                              // [S4]   D[u, :]
-    float* c1 = Dl + S4;                              // [kPosChunk] 1 - p_k, -inf for non-positives
+    const int64_t u = blockIdx.x;
+    float* sp = BIG ? sp_ws + u * (int64_t)S4 : reinterpret_cast<float*>(smem_raw);   // [S4] scores, tail -inf
+    float* Dl = BIG ? Dg + u * (int64_t)S : sp + S4;                                   // [S]  D[u, :]
+    float* c1 = BIG ? reinterpret_cast<float*>(smem_raw) : Dl + S4;  // [kPosChunk] 1 - p_k, -inf for non-positives
     float* wl = c1 + kPosChunk;                       // [kPosChunk] w_k
     float* dl = wl + kPosChunk;                       // [kPosChunk] delta_k
     float* red = dl + kPosChunk;                      // [kWaves][LD] + 2*kWaves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), grp = lane / G, gid = wave * NG + grp;
-    const int64_t u = blockIdx.x;
     const int64_t rb = rowptr[u], re = rowptr[u + 1];
     const int32_t* Ru = R + u * (int64_t)S;
 
@@ -83,8 +86,8 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
             }
         }
         for (int s = tid; s < S4; s += kThreads) {
-            Dl[s] = 0.f;
-            if (s >= S) sp[s] = -INFINITY;
+            if (s < S) Dl[s] = 0.f;
+            else sp[s] = -INFINITY;
         }
         __syncthreads();
 
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
 #pragma unroll
             for (int t = 0; t < kUnrollW; ++t) axpy<NV>(acc, d[t], y[t]);
         }
-        for (int s = tid; s < S; s += kThreads) Dg[u * (int64_t)S + s] = Dl[s];
+        if (!BIG)
+            for (int s = tid; s < S; s += kThreads) Dg[u * (int64_t)S + s] = Dl[s];
     }
 
     // ---- block reduction of gU (groups of a wave, then the four waves in order) and of the loss ----
@@ -228,19 +232,29 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     }
 }
 
+static size_t wmrb_user_lds(int S, int ld, bool big) {
+    return sizeof(float) * ((big ? 0 : (size_t)2 * round4(S)) + 3 * kPosChunk + (size_t)kWaves * ld + 2 * kWaves);
+}
+
 template <int G, int NV, bool SLICED>
 static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
-                            const float* sp_in, int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
+                            const float* sp_in, float* sp_ws, int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
                             float* U_out, float* delta, float* D, float* loss_part, float* pos_part, int epi,
                             tmf_adam adam, hipStream_t stream) {
-    const size_t lds = sizeof(float) * ((size_t)2 * round4(S) + 3 * kPosChunk + (size_t)kWaves * 4 * G * NV + 2 * kWaves);
-    if (lds > 160 * 1024) {
-        set_error("wmrb_user_pass: n_samples=%d needs %zu bytes of LDS (max 163840)", S, lds);
-        return TMF_E_UNSUPPORTED;
+    const bool big = wmrb_user_lds(S, 4 * G * NV, false) > 160 * 1024;
+    const size_t lds = wmrb_user_lds(S, 4 * G * NV, big);
+    if (big) {
+        if (SLICED || sp_ws == nullptr) {
+            set_error("wmrb_user_pass: n_samples=%d does not fit LDS; pass the workspace of tmf_wmrb_user_workspace_bytes()", S);
+            return TMF_E_INVALID;
+        }
+        hipLaunchKernelGGL((k_wmrb_user<G, NV, false, true>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr,
+                           col, val, R, sp_in, sp_ws, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
+        return check_launch("tmf_wmrb_user_pass_f32");
     }
     static size_t allowed = 64 * 1024;  // per template instance
     if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, SLICED>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, SLICED, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
@@ -248,8 +262,8 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
         }
         allowed = lds;
     }
-    hipLaunchKernelGGL((k_wmrb_user<G, NV, SLICED>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
-                       val, R, sp_in, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
+    hipLaunchKernelGGL((k_wmrb_user<G, NV, SLICED, false>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
+                       val, R, sp_in, sp_ws, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
     return check_launch(SLICED ? "tmf_wmrb_hinge_f32" : "tmf_wmrb_user_pass_f32");
 }
 
@@ -332,19 +346,26 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* __restric
 
 using namespace tmf;
 
+extern "C" size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int n_components) {
+    const RowGeom geom = row_geom(n_components);
+    if (geom.ld == 0 || S <= 0 || n_users <= 0) return 0;
+    if (wmrb_user_lds(S, geom.ld, false) <= 160 * 1024) return 0;
+    return (size_t)n_users * round4(S) * sizeof(float);
+}
+
 extern "C" int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                       const int32_t* R, int32_t n_users, int32_t S, float c,
                                       const float* U_old, const float* V_old, float* U_out, float* delta,
-                                      float* D, float* loss_part, float* pos_part, int n_components, int epi,
-                                      tmf_adam adam, void* stream) {
+                                      float* D, float* loss_part, float* pos_part, float* workspace,
+                                      int n_components, int epi, tmf_adam adam, void* stream) {
     if (n_users == 0) return TMF_OK;
     TMF_REQUIRE(n_users > 0 && S > 0, "wmrb_user_pass: n_users=%d S=%d", n_users, S);
     TMF_REQUIRE(rowptr && R && U_old && V_old && U_out && D, "wmrb_user_pass: null pointer");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_user_pass: bad epilogue %d", epi);
     const RowGeom geom = row_geom(n_components);
 #define CALL(G_, NV_)                                                                                           \
-    return launch_wmrb_user<G_, NV_, false>(rowptr, col, val, R, nullptr, n_users, S, c, U_old, V_old, U_out, delta, D, \
-                                            loss_part, pos_part, epi, adam, (hipStream_t)stream)
+    return launch_wmrb_user<G_, NV_, false>(rowptr, col, val, R, nullptr, workspace, n_users, S, c, U_old, V_old, U_out, \
+                                            delta, D, loss_part, pos_part, epi, adam, (hipStream_t)stream)
     TMF_DISPATCH_GEOM(geom, CALL);
 #undef CALL
     return TMF_OK;
@@ -376,8 +397,8 @@ extern "C" int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, con
     const RowGeom geom = row_geom(n_components);
     tmf_adam none = {0.f, 0.f, 0.f, 0.f};
 #define CALL(G_, NV_)                                                                                                  \
-    return launch_wmrb_user<G_, NV_, true>(rowptr, col, val, nullptr, sp, n_users, S, c, U_old, V_old, gpos, delta, D, \
-                                           loss_part, nullptr, TMF_EPI_GRAD, none, (hipStream_t)stream)
+    return launch_wmrb_user<G_, NV_, true>(rowptr, col, val, nullptr, sp, nullptr, n_users, S, c, U_old, V_old, gpos, delta, \
+                                           D, loss_part, nullptr, TMF_EPI_GRAD, none, (hipStream_t)stream)
     TMF_DISPATCH_GEOM(geom, CALL);
 #undef CALL
     return TMF_OK;

@@ -8,6 +8,7 @@ combination of plug-ins (dense features, biased / ReLU embeddings, KL loss, user
 through ``_fit_generic``: the reference's dense loop written with torch autograd around the plug-ins'
 own ``get_repr`` / ``get_loss``.
 """
+import os
 import timeit
 
 import numpy as np
@@ -21,6 +22,8 @@ from .sparse import IndicatorFeatures, SparseInteractions, default_device, is_in
 from .utils import gather_matrix_indices, random_sampler
 
 PREDICT_CHUNK_BYTES = 2 << 30  # users are scored in blocks of at most this many bytes of scores
+GRAPH_EPOCHS = 50              # epochs captured per hipGraph on launch-bound problems
+GRAPH_MAX_WORK = 20_000_000    # interactions + sampled scores per epoch below which fit() uses graphs
 
 
 class SampleTableMissing(AttributeError):
@@ -133,14 +136,39 @@ class MatrixFactorization:
         loss_sums = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
         denom = plan.n_pos if wmrb else plan.nnz
         self.loss_history_ = []
+        def run_epoch(epoch, out):
+            if wmrb:
+                _engine.epoch_wmrb(st, adam, c, out)
+            else:
+                _engine.epoch_mse(st, adam, out)
+            st.swap()
+
+        # Launch-bound problems (a few hundred microseconds of kernels per epoch): capture an even number of
+        # epochs into one hipGraph and replay it - the per-launch host cost disappears from the loop.
+        work = plan.nnz + (plan.n_users * wplan.S if wmrb else 0)
+        G = min(epochs - epochs % 2, GRAPH_EPOCHS)
+        use_graph = (G >= 4 and work <= GRAPH_MAX_WORK and os.environ.get('TMF_NO_GRAPH') is None
+                     and not (wmrb and wplan.n_slices > 1))
         torch.cuda.synchronize(dev)
         t0 = timeit.default_timer()
-        for epoch in range(epochs):
-            if wmrb:
-                _engine.epoch_wmrb(st, adam, c, loss_sums[epoch:epoch + 1])
-            else:
-                _engine.epoch_mse(st, adam, loss_sums[epoch:epoch + 1])
-            st.swap()
+        done = 0
+        if use_graph:
+            block = torch.zeros(G, dtype=torch.float64, device=dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for e in range(G):
+                    run_epoch(e, block[e:e + 1])
+            # capture only records; the tables are still the initial ones (G is even: buffers line up again)
+            while done + G <= epochs:
+                graph.replay()
+                loss_sums[done:done + G].copy_(block)
+                done += G
+                if self.verbose and denom:
+                    for e in range(done - G, done):
+                        if (e + 1) % 25 == 0:
+                            self._report(e, float(loss_sums[e]) / denom, (timeit.default_timer() - t0) * (e + 1) / done)
+        for epoch in range(done, epochs):
+            run_epoch(epoch, loss_sums[epoch:epoch + 1])
             if self.verbose and (epoch + 1) % 25 == 0:
                 loss = float(loss_sums[epoch]) / denom if denom else float('nan')  # syncs
                 self._report(epoch, loss, timeit.default_timer() - t0)

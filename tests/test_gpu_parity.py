@@ -114,6 +114,39 @@ def test_c1_full_run_predict_topk_recall(tm, golden):
     assert unobs.shape[0] == int((g['A'] == 0).sum())
 
 
+def test_remaining_metrics_match_dense_oracle(tm, golden):
+    """precision / f1 / dcg / idcg / ndcg / predict_ranks / predict(A) / save_model."""
+    from oracle import dense_ref as D
+    for name, e in (('c1_mse', 450), ('wmrb_mixed', 10)):
+        g = golden(name)
+        U, V, A = g[f'U_{e}'], g[f'V_{e}'], g['A']
+        model = tm.MF(U.shape[1], n_users=A.shape[0], n_items=A.shape[1])
+        model.user_embedding, model.item_embedding = torch.tensor(U).cuda(), torch.tensor(V).cuda()
+        At = torch.tensor(A)
+        for k in (1, 10):
+            assert np.array_equal(model.precision_at_k(At, k).cpu().numpy(), D.precision_at_k_dense(U, V, A, k))
+            assert np.array_equal(model.precision_at_k(At, k, preserve_rows=True).cpu().numpy(),
+                                  D.precision_at_k_dense(U, V, A, k, preserve_rows=True))
+            assert abs(float(model.f1_at_k(At, k)) - float(D.f1_at_k_dense(U, V, A, k))) < 1e-6
+            assert rel_err(model.dcg_at_k(At, k).cpu().numpy(), D.dcg_at_k_dense(U, V, A, k)) < 1e-5
+            assert rel_err(model.idcg_at_k(At, k).cpu().numpy(), D.dcg_at_k_dense(U, V, A, k, ideal=True)) < 1e-5
+            got, want = model.ndcg_at_k(At, k).cpu().numpy(), D.ndcg_at_k_dense(U, V, A, k)
+            assert got.shape == want.shape and np.allclose(got, want, rtol=1e-5, atol=1e-7, equal_nan=True)
+            got = model.ndcg_at_k(At, k, preserve_rows=True).cpu().numpy()
+            assert np.allclose(got, D.ndcg_at_k_dense(U, V, A, k, preserve_rows=True), rtol=1e-5, atol=1e-7)
+        allp, unobs = model.predict(At)
+        want_all, want_un = D.predict_dense(U, V, A)
+        assert rel_err(unobs.cpu().numpy(), want_un) < 1e-5 and unobs.shape[0] == want_un.shape[0]
+        ranks = model.predict_ranks(At).cpu().numpy()
+        # ranking of fp32 scores: compare through the values they select (ties / 1-ulp differences aside)
+        assert np.array_equal(np.sort(ranks), np.arange(len(want_un)))
+        assert rel_err(unobs.cpu().numpy()[ranks], want_un[D.predict_ranks_dense(U, V, A)]) < 1e-5
+        cfg, res = model.save_model()
+        assert cfg['Latent Dimension'] == U.shape[1] and res['User Embedding'] is model.user_embedding
+        again = tm.MF.from_saved(cfg)
+        assert again.n_components == U.shape[1] and again.n_items == A.shape[1]
+
+
 def test_c2_mse(tm, golden):
     g = golden('c2_mse')
     idx, val, A, U0, V0 = MG.c2_inputs()
@@ -208,6 +241,21 @@ def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices):
     V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
     R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
     check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
+
+
+def test_wmrb_n_samples_beyond_lds_uses_global_workspace(tm):
+    """S = 30000 negatives per user: 240 KB of scores + D per user do not fit the 160 KB of LDS."""
+    rng = np.random.default_rng(3)
+    m, n, r, S_ = 5, 40000, 8, 30000
+    idx = np.stack([rng.integers(0, m, 60), rng.integers(0, n, 60)], axis=1)
+    idx = np.unique(idx, axis=0)
+    val = rng.integers(-1, 6, len(idx)).astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
+    model, t = check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
+    assert model._state.user_ws is not None
+    assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
 
 
 def test_heavy_rows_are_segmented_and_combined(tm):
@@ -306,6 +354,22 @@ def test_predict_gemm_shapes(tm):
         got = tm.ops.predict_gemm(U, V).cpu().numpy()
         want = (U.double() @ V.double().T).numpy()
         assert rel_err(got, want) < 1e-5, (m, n, r)
+
+
+def test_graph_replay_equals_eager(tm, golden, monkeypatch):
+    """fit() replays hipGraph-captured epochs on small problems; results must equal the eager launches bit for bit."""
+    g = golden('wmrb_small')
+    args = (g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape)
+    for epochs in (10, 13, 120):
+        a = fit_model(tm, *args, epochs, 0.1, 'wmrb', g['R'], 100, 50)
+        m = fit_model(tm, *args, epochs, 0.01)
+        monkeypatch.setenv('TMF_NO_GRAPH', '1')
+        b = fit_model(tm, *args, epochs, 0.1, 'wmrb', g['R'], 100, 50)
+        n = fit_model(tm, *args, epochs, 0.01)
+        monkeypatch.delenv('TMF_NO_GRAPH')
+        assert a.loss_history_ == b.loss_history_ and torch.equal(a.user_embedding, b.user_embedding)
+        assert torch.equal(a.item_embedding, b.item_embedding)
+        assert m.loss_history_ == n.loss_history_ and torch.equal(m.item_embedding, n.item_embedding)
 
 
 def test_wmrb_without_sample_table_raises(tm):
