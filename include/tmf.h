@@ -48,6 +48,9 @@ const char* tmf_last_error(void);
  * Returns 0 when n_components is outside [1, 1024]. */
 int tmf_padded_ld(int n_components);
 
+/* Same for bf16-stored tables (8 elements per 16-byte lane): the next 8 x power-of-two (<= 512), else 1024. */
+int tmf_padded_ld_bf16(int n_components);
+
 /* Scalars of one Keras Adam step at iteration 1 with zero moments, in fp32 - the reference builds
  * a new optimizer every epoch (matrix_factorization.py:176), so this is the whole optimizer state.
  *   alpha = lr*sqrt(1-b2)/(1-b1), one_minus_b1, one_minus_b2, eps = 1e-7 */
@@ -155,6 +158,28 @@ int tmf_predict_gemm_f32(const float* A, const float* B, float* C, int64_t m, in
  * (matrix_factorization.py:237).  out_idx [rows, k] int32, out_val optional [rows, k]. */
 int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, int k,
                         int clamp_negatives, int32_t* out_idx, float* out_val, void* stream);
+
+/* bf16-storage / fp32-arithmetic variants (BASELINE config 5: "bf16 factors / fp32 accum"; an extension - the
+ * reference is fp32 throughout).  Tables are bf16 row-major [rows, tmf_padded_ld_bf16(r)]; every product,
+ * sum, loss and the optimiser step are computed in fp32 and the new row is rounded to bf16 once
+ * (round-to-nearest-even).  slab / loss / delta / D / TMF_EPI_GRAD outputs stay fp32 (the raw gradient is what
+ * RCCL reduce-scatters).  Arguments otherwise exactly as the _f32 functions. */
+int tmf_mse_pass_bf16(const tmf_segments* seg, const int32_t* other, const float* val,
+                      const void* X_old, const void* Y_old, void* X_out, float* slab,
+                      float* loss_part, int n_components, int epi, tmf_adam adam, void* stream);
+int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w,
+                       const float* wbuf, const void* T, const void* X_old, void* X_out,
+                       float* slab, int n_components, int epi, tmf_adam adam, void* stream);
+int tmf_combine_rows_bf16(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
+                          const float* slab, const void* X_old, void* X_out, int n_components,
+                          int epi, tmf_adam adam, void* stream);
+int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col, const float* val,
+                            const int32_t* R, int32_t n_users, int32_t S, float c,
+                            const void* U_old, const void* V_old, void* U_out, float* delta,
+                            float* D, float* loss_part, float* pos_part, float* workspace,
+                            int n_components, int epi, tmf_adam adam, void* stream);
+int tmf_adam_fresh_rows_bf16(void* W, const float* G, int64_t n_rows, int n_components,
+                             tmf_adam adam, void* stream);
 
 /* K7+K8 fused: out_idx[u, :k] = top-k (value desc, index asc) of A[u, :r] . B[:, :r]^T over all n items,
  * without materialising the [m, n] scores (recall_at_k / retrieve_user_recs, matrix_factorization.py:236-248,

@@ -200,10 +200,16 @@ class WmrbPlan:
 class TrainState:
     """Double-buffered factor tables [rows, ld] and the scratch the passes need."""
 
-    def __init__(self, U0, V0, plan, n_components, wplan=None):
+    def __init__(self, U0, V0, plan, n_components, wplan=None, dtype=torch.float32):
         dev = plan.col_u.device
         self.r = int(n_components)
-        self.ld = _lib.padded_ld(self.r)
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('factor tables are stored as float32 or bfloat16')
+        if dtype is torch.bfloat16 and wplan is not None and wplan.n_slices > 1:
+            raise ValueError('the sliced WMRB user pass is fp32 only')
+        self.dtype = dtype
+        self.sfx = '_bf16' if dtype is torch.bfloat16 else '_f32'
+        self.ld = _lib.padded_ld(self.r, dtype)
         self.U = self._pad(U0, dev)
         self.V = self._pad(V0, dev)
         self.U_nxt = torch.empty_like(self.U)
@@ -227,8 +233,8 @@ class TrainState:
 
     def _pad(self, W, dev):
         W = torch.as_tensor(W).detach().to(device=dev, dtype=torch.float32)
-        out = torch.zeros(W.shape[0], self.ld, dtype=torch.float32, device=dev)
-        out[:, :self.r] = W
+        out = torch.zeros(W.shape[0], self.ld, dtype=self.dtype, device=dev)
+        out[:, :self.r] = W  # bf16: round-to-nearest-even, like the kernels' stores
         return out
 
     def swap(self):
@@ -258,9 +264,9 @@ class KernelTimer:
         return sum(v) / len(v) if v else float('nan')
 
 
-def _row_pass_finish(lib, seg, slab, X_old, X_out, r, epi, adam, stream):
+def _row_pass_finish(lib, seg, slab, X_old, X_out, r, epi, adam, stream, sfx='_f32'):
     if seg.n_long:
-        _lib.check(lib.tmf_combine_rows_f32(_lib.ptr(seg.long_rows), _lib.ptr(seg.long_slab_beg), seg.n_long,
+        _lib.check(getattr(lib, 'tmf_combine_rows' + sfx)(_lib.ptr(seg.long_rows), _lib.ptr(seg.long_slab_beg), seg.n_long,
                                             _lib.ptr(slab), _lib.ptr(X_old), _lib.ptr(X_out), r, epi, adam, stream), lib)
 
 
@@ -272,21 +278,22 @@ def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=No
     s = _lib.stream_ptr()
     if prof:
         prof.start('mse_user_pass')
-    _lib.check(lib.tmf_mse_pass_f32(p.seg_u.cstruct(), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.U),
+    mse_pass = getattr(lib, 'tmf_mse_pass' + st.sfx)
+    _lib.check(mse_pass(p.seg_u.cstruct(), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.U),
                                     _lib.ptr(st.V), _lib.ptr(st.U_nxt), _lib.ptr(st.slab), _lib.ptr(st.loss_part),
                                     r, _lib.EPI_ADAM, adam, s), lib)
     if prof:
         prof.stop('mse_user_pass')
-    _row_pass_finish(lib, p.seg_u, st.slab, st.U, st.U_nxt, r, _lib.EPI_ADAM, adam, s)
+    _row_pass_finish(lib, p.seg_u, st.slab, st.U, st.U_nxt, r, _lib.EPI_ADAM, adam, s, st.sfx)
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.seg_u.nseg, _lib.ptr(loss_out), s), lib)
     V_out = st.V_nxt if item_out is None else item_out
     if prof:
         prof.start('mse_item_pass')
-    _lib.check(lib.tmf_mse_pass_f32(p.seg_i.cstruct(), _lib.ptr(p.row_i), _lib.ptr(p.val_i), _lib.ptr(st.V),
+    _lib.check(mse_pass(p.seg_i.cstruct(), _lib.ptr(p.row_i), _lib.ptr(p.val_i), _lib.ptr(st.V),
                                     _lib.ptr(st.U), _lib.ptr(V_out), _lib.ptr(st.slab), None, r, item_epi, adam, s), lib)
     if prof:
         prof.stop('mse_item_pass')
-    _row_pass_finish(lib, p.seg_i, st.slab, st.V, V_out, r, item_epi, adam, s)
+    _row_pass_finish(lib, p.seg_i, st.slab, st.V, V_out, r, item_epi, adam, s, st.sfx)
 
 
 def _wmrb_user_pass_sliced(lib, st, adam, c):
@@ -338,7 +345,7 @@ def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, pro
     if w.n_slices > 1:
         _wmrb_user_pass_sliced(lib, st, adam, c)
     else:
-        _lib.check(lib.tmf_wmrb_user_pass_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
+        _lib.check(getattr(lib, 'tmf_wmrb_user_pass' + st.sfx)(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
                                               p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
                                               _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None,
                                               _lib.ptr(st.user_ws), r, _lib.EPI_ADAM, adam, s), lib)
@@ -348,12 +355,12 @@ def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, pro
     V_out = st.V_nxt if item_out is None else item_out
     if prof:
         prof.start('wmrb_item_pass')
-    _lib.check(lib.tmf_wsum_pass_f32(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf),
+    _lib.check(getattr(lib, 'tmf_wsum_pass' + st.sfx)(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf),
                                      _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(V_out), _lib.ptr(st.slab), r, item_epi,
                                      adam, s), lib)
     if prof:
         prof.stop('wmrb_item_pass')
-    _row_pass_finish(lib, w.seg_e, st.slab, st.V, V_out, r, item_epi, adam, s)
+    _row_pass_finish(lib, w.seg_e, st.slab, st.V, V_out, r, item_epi, adam, s, st.sfx)
 
 
 def adam_constants(lr):

@@ -42,6 +42,7 @@ SIGNATURES = {
     'tmf_version': (_I, []),
     'tmf_last_error': (ctypes.c_char_p, []),
     'tmf_padded_ld': (_I, [_I]),
+    'tmf_padded_ld_bf16': (_I, [_I]),
     'tmf_adam_fresh': (Adam, [_F]),
     'tmf_mse_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
@@ -54,6 +55,12 @@ SIGNATURES = {
     'tmf_wmrb_gradu_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
     'tmf_wmrb_finish_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _I, _I, Adam, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
+    'tmf_mse_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_wsum_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_combine_rows_bf16': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_wmrb_user_pass_bf16': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P, _P,
+                                      _I, _I, Adam, _P]),
+    'tmf_adam_fresh_rows_bf16': (_I, [_P, _P, _L, _I, Adam, _P]),
     'tmf_sum_f32': (_I, [_P, _L, _P, _P]),
     'tmf_gather_rows_cols_f32': (_I, [_P, _P, _P, _L, _L, _L, _P]),
     'tmf_predict_gemm_f32': (_I, [_P, _P, _P, _L, _L, _I, _L, _L, _L, _P]),
@@ -117,11 +124,18 @@ def check(rc, lib=None):
         raise EngineError(f'libtmf error {rc}: {lib.tmf_last_error().decode()}')
 
 
-def padded_ld(n_components):
-    """Mirror of tmf_padded_ld, usable without loading the library."""
+def padded_ld(n_components, dtype=None):
+    """Mirror of tmf_padded_ld / tmf_padded_ld_bf16, usable without loading the library."""
     r = int(n_components)
     if r < 1 or r > 1024:
         raise ValueError(f'n_components={r} outside the supported range [1, 1024]')
+    if dtype is torch.bfloat16:
+        if r > 512:
+            return 1024
+        lanes, g = (r + 7) // 8, 1
+        while g < lanes:
+            g *= 2
+        return 8 * g
     if r <= 256:
         lanes, g = (r + 3) // 4, 1
         while g < lanes:

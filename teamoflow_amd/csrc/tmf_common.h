@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "../../include/tmf.h"
 
 namespace tmf {
@@ -46,6 +48,27 @@ inline RowGeom row_geom(int r) {
     return g;
 }
 
+// bf16 storage: 8 elements (16 bytes) per lane and fragment pair.
+inline RowGeom row_geom_bf16(int r) {
+    RowGeom g{0, 0, 0};
+    if (r < 1 || r > 1024) return g;
+    if (r <= 512) {
+        int lanes = (r + 7) / 8, G = 1;
+        while (G < lanes) G <<= 1;
+        g = {G, 2, 8 * G};
+    } else {
+        g = {64, 4, 1024};
+    }
+    return g;
+}
+
+template <typename T>
+inline RowGeom row_geom_of(int r);
+template <>
+inline RowGeom row_geom_of<float>(int r) { return row_geom(r); }
+template <>
+inline RowGeom row_geom_of<__bf16>(int r) { return row_geom_bf16(r); }
+
 // Dispatch a callable templated on <G, NV> for the geometry of rank r.
 #define TMF_DISPATCH_GEOM(geom, CALL)                       \
     switch ((geom).G * 8 + (geom).NV) {                     \
@@ -62,12 +85,53 @@ inline RowGeom row_geom(int r) {
             return TMF_E_UNSUPPORTED;                       \
     }
 
+#define TMF_DISPATCH_GEOM_BF16(geom, CALL)                  \
+    switch ((geom).G * 8 + (geom).NV) {                     \
+        case 1 * 8 + 2: { CALL(1, 2); } break;              \
+        case 2 * 8 + 2: { CALL(2, 2); } break;              \
+        case 4 * 8 + 2: { CALL(4, 2); } break;              \
+        case 8 * 8 + 2: { CALL(8, 2); } break;              \
+        case 16 * 8 + 2: { CALL(16, 2); } break;            \
+        case 32 * 8 + 2: { CALL(32, 2); } break;            \
+        case 64 * 8 + 2: { CALL(64, 2); } break;            \
+        case 64 * 8 + 4: { CALL(64, 4); } break;            \
+        default: tmf::set_error("unsupported n_components"); \
+            return TMF_E_UNSUPPORTED;                       \
+    }
+
+// selection of the dispatch table by storage type (use inside a function templated on T_)
+#define TMF_DISPATCH(T_, geom, CALL)                                                 \
+    if constexpr (std::is_same<T_, float>::value) { TMF_DISPATCH_GEOM(geom, CALL); } \
+    else { TMF_DISPATCH_GEOM_BF16(geom, CALL); }
+
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
 template <int NV>
 struct Frag {
     float4 v[NV];
+};
+
+// Storage types of a factor table: float, or __bf16 (bf16 storage / fp32 arithmetic, BASELINE config 5).
+// A lane's registers always hold NV float4; what differs is which elements of the row they are:
+//   float : fragment v = elements [4 (g + G v), +4)                     (one 16-byte load per fragment)
+//   __bf16: fragments 2p, 2p+1 = elements [8 (g + G p), +8)             (one 16-byte load per PAIR)
+// so that every load instruction of a group is one contiguous 16*G-byte piece of the row either way.
+// fp32 side arrays that belong to a table of storage type T (slab partials, raw gradients) are
+// written in natural element order through the same element map (load/store_row_f32).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <int G, int NV, typename T>
+struct RowMap;
+template <int G, int NV>
+struct RowMap<G, NV, float> {
+    static __device__ __forceinline__ int off(int v, int g) { return 4 * (g + G * v); }
+};
+template <int G, int NV>
+struct RowMap<G, NV, __bf16> {
+    static_assert(NV % 2 == 0, "bf16 rows are loaded in pairs of fragments");
+    static __device__ __forceinline__ int off(int v, int g) { return 8 * (g + G * (v >> 1)) + 4 * (v & 1); }
 };
 
 template <int G, int NV>
@@ -78,10 +142,47 @@ __device__ __forceinline__ void load_row(Frag<NV>& f, const float* __restrict__ 
 }
 
 template <int G, int NV>
+__device__ __forceinline__ void load_row(Frag<NV>& f, const __bf16* __restrict__ T, int64_t row, int g) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(T + row * (int64_t)(4 * G * NV)) + g;
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv) {
+        const f32x8 w = __builtin_convertvector(p[G * pv], f32x8);
+        f.v[2 * pv] = make_float4(w[0], w[1], w[2], w[3]);
+        f.v[2 * pv + 1] = make_float4(w[4], w[5], w[6], w[7]);
+    }
+}
+
+template <int G, int NV>
 __device__ __forceinline__ void store_row(const Frag<NV>& f, float* __restrict__ T, int64_t row, int g) {
     float4* p = reinterpret_cast<float4*>(T + row * (int64_t)(4 * G * NV)) + g;
 #pragma unroll
     for (int v = 0; v < NV; ++v) p[G * v] = f.v[v];
+}
+
+template <int G, int NV>
+__device__ __forceinline__ void store_row(const Frag<NV>& f, __bf16* __restrict__ T, int64_t row, int g) {
+    bf16x8* p = reinterpret_cast<bf16x8*>(T + row * (int64_t)(4 * G * NV)) + g;
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv) {
+        f32x8 w;
+        w[0] = f.v[2 * pv].x; w[1] = f.v[2 * pv].y; w[2] = f.v[2 * pv].z; w[3] = f.v[2 * pv].w;
+        w[4] = f.v[2 * pv + 1].x; w[5] = f.v[2 * pv + 1].y; w[6] = f.v[2 * pv + 1].z; w[7] = f.v[2 * pv + 1].w;
+        p[G * pv] = __builtin_convertvector(w, bf16x8);  // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    }
+}
+
+template <int G, int NV, typename T>
+__device__ __forceinline__ void load_row_f32(Frag<NV>& f, const float* __restrict__ B, int64_t row, int g) {
+    const float* p = B + row * (int64_t)(4 * G * NV);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) f.v[v] = *reinterpret_cast<const float4*>(p + RowMap<G, NV, T>::off(v, g));
+}
+
+template <int G, int NV, typename T>
+__device__ __forceinline__ void store_row_f32(const Frag<NV>& f, float* __restrict__ B, int64_t row, int g) {
+    float* p = B + row * (int64_t)(4 * G * NV);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(p + RowMap<G, NV, T>::off(v, g)) = f.v[v];
 }
 
 template <int NV>
@@ -173,18 +274,18 @@ __device__ __forceinline__ void adam_fresh(Frag<NV>& w, const Frag<NV>& g, const
     }
 }
 
-// Epilogue shared by every row pass: lanes of group 0 write the row.
-template <int G, int NV>
-__device__ __forceinline__ void row_epilogue(const Frag<NV>& g, const float* __restrict__ X_old,
-                                             float* __restrict__ X_out, int64_t row, int lane_in_group,
-                                             int epi, const tmf_adam adam) {
+// Epilogue shared by every row pass: lanes of group 0 write the row.  TMF_EPI_GRAD writes the raw fp32
+// gradient (natural element order) whatever the table's storage type.
+template <int G, int NV, typename T>
+__device__ __forceinline__ void row_epilogue(const Frag<NV>& g, const T* __restrict__ X_old, void* __restrict__ X_out,
+                                             int64_t row, int lane_in_group, int epi, const tmf_adam adam) {
     if (epi == TMF_EPI_GRAD) {
-        store_row<G, NV>(g, X_out, row, lane_in_group);
+        store_row_f32<G, NV, T>(g, static_cast<float*>(X_out), row, lane_in_group);
     } else {
         Frag<NV> w;
         load_row<G, NV>(w, X_old, row, lane_in_group);
         adam_fresh<NV>(w, g, adam);
-        store_row<G, NV>(w, X_out, row, lane_in_group);
+        store_row<G, NV>(w, static_cast<T*>(X_out), row, lane_in_group);
     }
 }
 

@@ -30,6 +30,8 @@ extern "C" const char* tmf_last_error(void) { return tmf::g_err; }
 
 extern "C" int tmf_padded_ld(int n_components) { return tmf::row_geom(n_components).ld; }
 
+extern "C" int tmf_padded_ld_bf16(int n_components) { return tmf::row_geom_bf16(n_components).ld; }
+
 extern "C" tmf_adam tmf_adam_fresh(float lr) {
     // fp32 throughout, like tf.keras.optimizers.Adam at iterations == 0 (beta^1 = beta)
     const float one = 1.0f, b1 = 0.9f, b2 = 0.999f;

@@ -23,10 +23,10 @@ struct SegView {
 // segment, kUnroll entries in flight per group.  p_k is reduced over the group with xor shuffles,
 // the gradient row is accumulated in registers and reduced over the groups once at the end.
 // ---------------------------------------------------------------------------------------------
-template <int G, int NV>
+template <int G, int NV, typename T>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
     SegView sv, const int32_t* __restrict__ other, const float* __restrict__ val,
-    const float* __restrict__ X_old, const float* __restrict__ Y_old, float* __restrict__ X_out,
+    const T* __restrict__ X_old, const T* __restrict__ Y_old, void* __restrict__ X_out,
     float* __restrict__ slab, float* __restrict__ loss_part, int epi, tmf_adam adam) {
     constexpr int NG = 64 / G;
     const int lane = threadIdx.x & 63;
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
     }
     if (grp == 0) {
         const int slot = sv.seg_slab[seg];
-        if (slot < 0) row_epilogue<G, NV>(acc, X_old, X_out, row, g, epi, adam);
-        else store_row<G, NV>(acc, slab, slot, g);
+        if (slot < 0) row_epilogue<G, NV, T>(acc, X_old, X_out, row, g, epi, adam);
+        else store_row_f32<G, NV, T>(acc, slab, slot, g);
     }
 }
 
@@ -88,11 +88,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
 // next step are fetched while the rows of the current one are in flight, because a row is only
 // loaded when its weight is non-zero (two dependent reads otherwise).
 // ---------------------------------------------------------------------------------------------
-template <int G, int NV>
+template <int G, int NV, typename T>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
     SegView sv, const int32_t* __restrict__ ent_row, const int64_t* __restrict__ ent_w,
-    const float* __restrict__ wbuf, const float* __restrict__ T, const float* __restrict__ X_old,
-    float* __restrict__ X_out, float* __restrict__ slab, int epi, tmf_adam adam) {
+    const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
+    void* __restrict__ X_out, float* __restrict__ slab, int epi, tmf_adam adam) {
     constexpr int NG = 64 / G;
     const int lane = threadIdx.x & 63;
     const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
 #pragma unroll
         for (int t = 0; t < kUnroll; ++t) {
             wc[t] = w[t];
-            if (wc[t] != 0.f) load_row<G, NV>(y[t], T, src[t], g);
+            if (wc[t] != 0.f) load_row<G, NV>(y[t], Tab, src[t], g);
             else zero<NV>(y[t]);
         }
         k0 += (int64_t)NG * kUnroll;
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
     across_groups_sum<G, NV>(acc);
     if (grp == 0) {
         const int slot = sv.seg_slab[seg];
-        if (slot < 0) row_epilogue<G, NV>(acc, X_old, X_out, row, g, epi, adam);
-        else store_row<G, NV>(acc, slab, slot, g);
+        if (slot < 0) row_epilogue<G, NV, T>(acc, X_old, X_out, row, g, epi, adam);
+        else store_row_f32<G, NV, T>(acc, slab, slot, g);
     }
 }
 
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
 // Rows cut into several segments: sum the slab slots in slot order (group t takes slots t, t+NG..
 // then the fixed butterfly over groups), then the epilogue.
 // ---------------------------------------------------------------------------------------------
-template <int G, int NV>
+template <int G, int NV, typename T>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_combine_rows(
     const int32_t* __restrict__ long_rows, const int64_t* __restrict__ slab_beg, int64_t n_long,
-    const float* __restrict__ slab, const float* __restrict__ X_old, float* __restrict__ X_out, int epi,
+    const float* __restrict__ slab, const T* __restrict__ X_old, void* __restrict__ X_out, int epi,
     tmf_adam adam) {
     constexpr int NG = 64 / G;
     const int lane = threadIdx.x & 63;
@@ -165,11 +165,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_combine_rows(
     zero<NV>(acc);
     for (int64_t s = beg + grp; s < end; s += NG) {
         Frag<NV> y;
-        load_row<G, NV>(y, slab, s, g);
+        load_row_f32<G, NV, T>(y, slab, s, g);
         add<NV>(acc, y);
     }
     across_groups_sum<G, NV>(acc);
-    if (grp == 0) row_epilogue<G, NV>(acc, X_old, X_out, row, g, epi, adam);
+    if (grp == 0) row_epilogue<G, NV, T>(acc, X_old, X_out, row, g, epi, adam);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -185,6 +185,19 @@ __global__ __launch_bounds__(256) void k_adam_rows(float4* __restrict__ W, const
         w.z = adam_fresh(w.z, g.z, adam);
         w.w = adam_fresh(w.w, g.w, adam);
         W[i] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adam_rows_bf16(bf16x8* __restrict__ W, const float4* __restrict__ Gr,
+                                                        int64_t n8, tmf_adam adam) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x8 w = __builtin_convertvector(W[i], f32x8);
+        const float4 a = Gr[2 * i], b = Gr[2 * i + 1];
+        w[0] = adam_fresh(w[0], a.x, adam); w[1] = adam_fresh(w[1], a.y, adam);
+        w[2] = adam_fresh(w[2], a.z, adam); w[3] = adam_fresh(w[3], a.w, adam);
+        w[4] = adam_fresh(w[4], b.x, adam); w[5] = adam_fresh(w[5], b.y, adam);
+        w[6] = adam_fresh(w[6], b.z, adam); w[7] = adam_fresh(w[7], b.w, adam);
+        W[i] = __builtin_convertvector(w, bf16x8);
     }
 }
 
@@ -220,56 +233,91 @@ static int check_segments(const tmf_segments* s) {
 
 using namespace tmf;
 
-extern "C" int tmf_mse_pass_f32(const tmf_segments* seg, const int32_t* other, const float* val,
-                                const float* X_old, const float* Y_old, float* X_out, float* slab,
-                                float* loss_part, int n_components, int epi, tmf_adam adam, void* stream) {
+template <typename T>
+static int mse_pass_impl(const tmf_segments* seg, const int32_t* other, const float* val, const void* X_old,
+                         const void* Y_old, void* X_out, float* slab, float* loss_part, int n_components, int epi,
+                         tmf_adam adam, void* stream) {
     if (int rc = check_segments(seg)) return rc;
     if (seg->nseg == 0) return TMF_OK;
     TMF_REQUIRE(X_old && Y_old && X_out, "mse_pass: null table");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "mse_pass: bad epilogue %d", epi);
-    const RowGeom geom = row_geom(n_components);
+    const RowGeom geom = row_geom_of<T>(n_components);
     const SegView sv = view(seg);
     const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
-#define CALL(G_, NV_)                                                                                    \
-    hipLaunchKernelGGL((k_mse_pass<G_, NV_>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
-                       sv, other, val, X_old, Y_old, X_out, slab, loss_part, epi, adam)
-    TMF_DISPATCH_GEOM(geom, CALL);
+#define CALL(G_, NV_)                                                                                          \
+    hipLaunchKernelGGL((k_mse_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       sv, other, val, (const T*)X_old, (const T*)Y_old, X_out, slab, loss_part, epi, adam)
+    TMF_DISPATCH(T, geom, CALL);
 #undef CALL
-    return check_launch("tmf_mse_pass_f32");
+    return check_launch("tmf_mse_pass");
+}
+
+template <typename T>
+static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w, const float* wbuf,
+                          const void* Tab, const void* X_old, void* X_out, float* slab, int n_components, int epi,
+                          tmf_adam adam, void* stream) {
+    if (int rc = check_segments(seg)) return rc;
+    if (seg->nseg == 0) return TMF_OK;
+    TMF_REQUIRE(Tab && X_out && (epi == TMF_EPI_GRAD || X_old), "wsum_pass: null table");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wsum_pass: bad epilogue %d", epi);
+    const RowGeom geom = row_geom_of<T>(n_components);
+    const SegView sv = view(seg);
+    const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
+#define CALL(G_, NV_)                                                                                           \
+    hipLaunchKernelGGL((k_wsum_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return check_launch("tmf_wsum_pass");
+}
+
+template <typename T>
+static int combine_rows_impl(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long, const float* slab,
+                             const void* X_old, void* X_out, int n_components, int epi, tmf_adam adam, void* stream) {
+    if (n_long == 0) return TMF_OK;
+    TMF_REQUIRE(n_long > 0 && long_rows && slab_beg && slab && X_out, "combine_rows: bad arguments");
+    TMF_REQUIRE(epi == TMF_EPI_GRAD || X_old, "combine_rows: X_old is null");
+    const RowGeom geom = row_geom_of<T>(n_components);
+    const unsigned blocks = (unsigned)((n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+#define CALL(G_, NV_)                                                                                              \
+    hipLaunchKernelGGL((k_combine_rows<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       long_rows, slab_beg, n_long, slab, (const T*)X_old, X_out, epi, adam)
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return check_launch("tmf_combine_rows");
+}
+
+extern "C" int tmf_mse_pass_f32(const tmf_segments* seg, const int32_t* other, const float* val,
+                                const float* X_old, const float* Y_old, float* X_out, float* slab,
+                                float* loss_part, int n_components, int epi, tmf_adam adam, void* stream) {
+    return mse_pass_impl<float>(seg, other, val, X_old, Y_old, X_out, slab, loss_part, n_components, epi, adam, stream);
+}
+extern "C" int tmf_mse_pass_bf16(const tmf_segments* seg, const int32_t* other, const float* val,
+                                 const void* X_old, const void* Y_old, void* X_out, float* slab,
+                                 float* loss_part, int n_components, int epi, tmf_adam adam, void* stream) {
+    return mse_pass_impl<__bf16>(seg, other, val, X_old, Y_old, X_out, slab, loss_part, n_components, epi, adam, stream);
 }
 
 extern "C" int tmf_wsum_pass_f32(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w,
                                  const float* wbuf, const float* T, const float* X_old, float* X_out,
                                  float* slab, int n_components, int epi, tmf_adam adam, void* stream) {
-    if (int rc = check_segments(seg)) return rc;
-    if (seg->nseg == 0) return TMF_OK;
-    TMF_REQUIRE(T && X_out && (epi == TMF_EPI_GRAD || X_old), "wsum_pass: null table");
-    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wsum_pass: bad epilogue %d", epi);
-    const RowGeom geom = row_geom(n_components);
-    const SegView sv = view(seg);
-    const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
-#define CALL(G_, NV_)                                                                                     \
-    hipLaunchKernelGGL((k_wsum_pass<G_, NV_>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
-                       sv, ent_row, ent_w, wbuf, T, X_old, X_out, slab, epi, adam)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return check_launch("tmf_wsum_pass_f32");
+    return wsum_pass_impl<float>(seg, ent_row, ent_w, wbuf, T, X_old, X_out, slab, n_components, epi, adam, stream);
+}
+extern "C" int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w,
+                                  const float* wbuf, const void* T, const void* X_old, void* X_out,
+                                  float* slab, int n_components, int epi, tmf_adam adam, void* stream) {
+    return wsum_pass_impl<__bf16>(seg, ent_row, ent_w, wbuf, T, X_old, X_out, slab, n_components, epi, adam, stream);
 }
 
 extern "C" int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
                                     const float* slab, const float* X_old, float* X_out, int n_components,
                                     int epi, tmf_adam adam, void* stream) {
-    if (n_long == 0) return TMF_OK;
-    TMF_REQUIRE(n_long > 0 && long_rows && slab_beg && slab && X_out, "combine_rows: bad arguments");
-    TMF_REQUIRE(epi == TMF_EPI_GRAD || X_old, "combine_rows: X_old is null");
-    const RowGeom geom = row_geom(n_components);
-    const unsigned blocks = (unsigned)((n_long + kWavesPerBlock - 1) / kWavesPerBlock);
-#define CALL(G_, NV_)                                                                                        \
-    hipLaunchKernelGGL((k_combine_rows<G_, NV_>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
-                       long_rows, slab_beg, n_long, slab, X_old, X_out, epi, adam)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return check_launch("tmf_combine_rows_f32");
+    return combine_rows_impl<float>(long_rows, slab_beg, n_long, slab, X_old, X_out, n_components, epi, adam, stream);
+}
+extern "C" int tmf_combine_rows_bf16(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
+                                     const float* slab, const void* X_old, void* X_out, int n_components,
+                                     int epi, tmf_adam adam, void* stream) {
+    return combine_rows_impl<__bf16>(long_rows, slab_beg, n_long, slab, X_old, X_out, n_components, epi, adam, stream);
 }
 
 extern "C" int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,
@@ -284,6 +332,20 @@ extern "C" int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows,
     hipLaunchKernelGGL(k_adam_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<float4*>(W), reinterpret_cast<const float4*>(G), n4, adam);
     return check_launch("tmf_adam_fresh_rows_f32");
+}
+
+extern "C" int tmf_adam_fresh_rows_bf16(void* W, const float* G, int64_t n_rows, int n_components,
+                                        tmf_adam adam, void* stream) {
+    if (n_rows == 0) return TMF_OK;
+    const RowGeom geom = row_geom_bf16(n_components);
+    TMF_REQUIRE(geom.ld > 0, "adam_fresh_rows: unsupported n_components %d", n_components);
+    TMF_REQUIRE(W && G && n_rows > 0, "adam_fresh_rows: bad arguments");
+    const int64_t n8 = n_rows * geom.ld / 8;
+    const int64_t want = (n8 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_adam_rows_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<bf16x8*>(W), reinterpret_cast<const float4*>(G), n8, adam);
+    return check_launch("tmf_adam_fresh_rows_bf16");
 }
 
 extern "C" int tmf_sum_f32(const float* x, int64_t n, double* out, void* stream) {

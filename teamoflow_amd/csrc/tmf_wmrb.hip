@@ -25,12 +25,12 @@ __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 // epilogue so that U_out receives only the positives' part  sum_k delta_k V[j_k].
 // BIG = true: n_samples too large for LDS - sp[u, :] and D[u, :] live in global memory (sp_ws row of
 // round4(S) floats per user, D's own row); same arithmetic, only the storage changes.
-template <int G, int NV, bool SLICED, bool BIG>
+template <int G, int NV, typename T, bool SLICED, bool BIG>
 __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     const int32_t* __restrict__ R, const float* __restrict__ sp_in, float* __restrict__ sp_ws, int S, float c,
-    const float* __restrict__ U_old,
-    const float* __restrict__ V_old, float* __restrict__ U_out, float* __restrict__ delta,
+    const T* __restrict__ U_old,
+    const T* __restrict__ V_old, void* __restrict__ U_out, float* __restrict__ delta,
     float* __restrict__ Dg, float* __restrict__ loss_part, float* __restrict__ pos_part, int epi,
     tmf_adam adam) {
     constexpr int NG = 64 / G;          // groups per wave
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
             for (int v = 0; v < NV; ++v) part.v[v] = reinterpret_cast<const float4*>(red + w * LD)[g + G * v];
             add<NV>(tot, part);
         }
-        row_epilogue<G, NV>(tot, U_old, U_out, u, g, epi, adam);
+        row_epilogue<G, NV, T>(tot, U_old, U_out, u, g, epi, adam);
     }
     if (tid == 0) {
         const float* t = red + kWaves * LD;
@@ -236,10 +236,10 @@ static size_t wmrb_user_lds(int S, int ld, bool big) {
     return sizeof(float) * ((big ? 0 : (size_t)2 * round4(S)) + 3 * kPosChunk + (size_t)kWaves * ld + 2 * kWaves);
 }
 
-template <int G, int NV, bool SLICED>
+template <int G, int NV, typename T, bool SLICED>
 static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
-                            const float* sp_in, float* sp_ws, int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
-                            float* U_out, float* delta, float* D, float* loss_part, float* pos_part, int epi,
+                            const float* sp_in, float* sp_ws, int32_t n_users, int32_t S, float c, const T* U_old, const T* V_old,
+                            void* U_out, float* delta, float* D, float* loss_part, float* pos_part, int epi,
                             tmf_adam adam, hipStream_t stream) {
     const bool big = wmrb_user_lds(S, 4 * G * NV, false) > 160 * 1024;
     const size_t lds = wmrb_user_lds(S, 4 * G * NV, big);
@@ -248,13 +248,13 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
             set_error("wmrb_user_pass: n_samples=%d does not fit LDS; pass the workspace of tmf_wmrb_user_workspace_bytes()", S);
             return TMF_E_INVALID;
         }
-        hipLaunchKernelGGL((k_wmrb_user<G, NV, false, true>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr,
+        hipLaunchKernelGGL((k_wmrb_user<G, NV, T, false, true>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr,
                            col, val, R, sp_in, sp_ws, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
         return check_launch("tmf_wmrb_user_pass_f32");
     }
     static size_t allowed = 64 * 1024;  // per template instance
     if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, SLICED, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, T, SLICED, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
@@ -262,7 +262,7 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
         }
         allowed = lds;
     }
-    hipLaunchKernelGGL((k_wmrb_user<G, NV, SLICED, false>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
+    hipLaunchKernelGGL((k_wmrb_user<G, NV, T, SLICED, false>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
                        val, R, sp_in, sp_ws, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
     return check_launch(SLICED ? "tmf_wmrb_hinge_f32" : "tmf_wmrb_user_pass_f32");
 }
@@ -281,10 +281,10 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 // ---------------------------------------------------------------------------------------------
 constexpr int kSliceUsers = 128;  // users per workgroup of k_wmrb_slice
 
-template <int G, int NV, bool GRADU>
+template <int G, int NV, typename T, bool GRADU>
 __global__ __launch_bounds__(kThreads) void k_wmrb_slice(
     const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
-    int64_t n_groups, const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ sp,
+    int64_t n_groups, const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp,
     const float* __restrict__ D, float* __restrict__ part) {
     constexpr int NG = 64 / G, NGB = NG * kWaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -320,26 +320,26 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_slice(
                 }
             }
         }
-        if (GRADU) store_row<G, NV>(acc, part, sl * n_users + u, g);
+        if (GRADU) store_row_f32<G, NV, T>(acc, part, sl * n_users + u, g);
     }
 }
 
-template <int G, int NV>
+template <int G, int NV, typename T>
 __global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* __restrict__ gpos, const float* __restrict__ part,
-                                                          int n_slices, int64_t n_users, const float* __restrict__ U_old,
-                                                          float* __restrict__ U_out, int epi, tmf_adam adam) {
+                                                          int n_slices, int64_t n_users, const T* __restrict__ U_old,
+                                                          void* __restrict__ U_out, int epi, tmf_adam adam) {
     constexpr int NG = 64 / G, NGB = NG * kWaves;
     const int lane = threadIdx.x & 63, g = lane & (G - 1);
     const int64_t u = (int64_t)blockIdx.x * NGB + (threadIdx.x >> 6) * NG + lane / G;
     if (u >= n_users) return;
     Frag<NV> acc;
-    load_row<G, NV>(acc, gpos, u, g);
+    load_row_f32<G, NV, T>(acc, gpos, u, g);
     for (int sl = 0; sl < n_slices; ++sl) {
         Frag<NV> y;
-        load_row<G, NV>(y, part, sl * n_users + u, g);
+        load_row_f32<G, NV, T>(y, part, sl * n_users + u, g);
         add<NV>(acc, y);
     }
-    row_epilogue<G, NV>(acc, U_old, U_out, u, g, epi, adam);
+    row_epilogue<G, NV, T>(acc, U_old, U_out, u, g, epi, adam);
 }
 
 }  // namespace tmf
@@ -353,22 +353,40 @@ extern "C" size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int 
     return (size_t)n_users * round4(S) * sizeof(float);
 }
 
+template <typename T>
+static int wmrb_user_pass_impl(const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
+                               int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old, void* U_out,
+                               float* delta, float* D, float* loss_part, float* pos_part, float* workspace,
+                               int n_components, int epi, tmf_adam adam, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(n_users > 0 && S > 0, "wmrb_user_pass: n_users=%d S=%d", n_users, S);
+    TMF_REQUIRE(rowptr && R && U_old && V_old && U_out && D, "wmrb_user_pass: null pointer");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_user_pass: bad epilogue %d", epi);
+    const RowGeom geom = row_geom_of<T>(n_components);
+#define CALL(G_, NV_)                                                                                                 \
+    return launch_wmrb_user<G_, NV_, T, false>(rowptr, col, val, R, nullptr, workspace, n_users, S, c, (const T*)U_old, \
+                                               (const T*)V_old, U_out, delta, D, loss_part, pos_part, epi, adam,       \
+                                               (hipStream_t)stream)
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return TMF_OK;
+}
+
 extern "C" int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                       const int32_t* R, int32_t n_users, int32_t S, float c,
                                       const float* U_old, const float* V_old, float* U_out, float* delta,
                                       float* D, float* loss_part, float* pos_part, float* workspace,
                                       int n_components, int epi, tmf_adam adam, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(n_users > 0 && S > 0, "wmrb_user_pass: n_users=%d S=%d", n_users, S);
-    TMF_REQUIRE(rowptr && R && U_old && V_old && U_out && D, "wmrb_user_pass: null pointer");
-    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_user_pass: bad epilogue %d", epi);
-    const RowGeom geom = row_geom(n_components);
-#define CALL(G_, NV_)                                                                                           \
-    return launch_wmrb_user<G_, NV_, false>(rowptr, col, val, R, nullptr, workspace, n_users, S, c, U_old, V_old, U_out, \
-                                            delta, D, loss_part, pos_part, epi, adam, (hipStream_t)stream)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return TMF_OK;
+    return wmrb_user_pass_impl<float>(rowptr, col, val, R, n_users, S, c, U_old, V_old, U_out, delta, D, loss_part,
+                                      pos_part, workspace, n_components, epi, adam, stream);
+}
+extern "C" int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col, const float* val,
+                                       const int32_t* R, int32_t n_users, int32_t S, float c,
+                                       const void* U_old, const void* V_old, void* U_out, float* delta,
+                                       float* D, float* loss_part, float* pos_part, float* workspace,
+                                       int n_components, int epi, tmf_adam adam, void* stream) {
+    return wmrb_user_pass_impl<__bf16>(rowptr, col, val, R, n_users, S, c, U_old, V_old, U_out, delta, D, loss_part,
+                                       pos_part, workspace, n_components, epi, adam, stream);
 }
 
 extern "C" int tmf_wmrb_scores_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
@@ -379,8 +397,8 @@ extern "C" int tmf_wmrb_scores_f32(const int32_t* R_sorted, const int32_t* slice
     const RowGeom geom = row_geom(n_components);
     const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
     TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_scores: grid too large");
-#define CALL(G_, NV_)                                                                                               \
-    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, false>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,       \
+#define CALL(G_, NV_)                                                                                                  \
+    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, float, false>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,   \
                        (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, U, V, sp, \
                        (const float*)nullptr, (float*)nullptr)
     TMF_DISPATCH_GEOM(geom, CALL);
@@ -396,9 +414,9 @@ extern "C" int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, con
     TMF_REQUIRE(rowptr && sp && U_old && V_old && gpos && D && n_users > 0 && S > 0, "wmrb_hinge: bad arguments");
     const RowGeom geom = row_geom(n_components);
     tmf_adam none = {0.f, 0.f, 0.f, 0.f};
-#define CALL(G_, NV_)                                                                                                  \
-    return launch_wmrb_user<G_, NV_, true>(rowptr, col, val, nullptr, sp, nullptr, n_users, S, c, U_old, V_old, gpos, delta, \
-                                           D, loss_part, nullptr, TMF_EPI_GRAD, none, (hipStream_t)stream)
+#define CALL(G_, NV_)                                                                                                   \
+    return launch_wmrb_user<G_, NV_, float, true>(rowptr, col, val, nullptr, sp, nullptr, n_users, S, c, U_old, V_old, gpos, \
+                                                  delta, D, loss_part, nullptr, TMF_EPI_GRAD, none, (hipStream_t)stream)
     TMF_DISPATCH_GEOM(geom, CALL);
 #undef CALL
     return TMF_OK;
@@ -412,9 +430,9 @@ extern "C" int tmf_wmrb_gradu_f32(const int32_t* R_sorted, const int32_t* slice_
     const RowGeom geom = row_geom(n_components);
     const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
     TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_gradu: grid too large");
-#define CALL(G_, NV_)                                                                                              \
-    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, true>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,       \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,     \
+#define CALL(G_, NV_)                                                                                                 \
+    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, float, true>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,   \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,      \
                        (const float*)nullptr, V, (float*)nullptr, D, part)
     TMF_DISPATCH_GEOM(geom, CALL);
 #undef CALL
@@ -428,12 +446,12 @@ extern "C" int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t
     TMF_REQUIRE(gpos && part && U_out && n_slices > 0 && (epi == TMF_EPI_GRAD || U_old), "wmrb_finish: bad arguments");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_finish: bad epilogue %d", epi);
     const RowGeom geom = row_geom(n_components);
-#define CALL(G_, NV_)                                                                                             \
-    {                                                                                                             \
-        constexpr int per_block = (64 / G_) * kWaves;                                                             \
-        hipLaunchKernelGGL((k_wmrb_finish<G_, NV_>), dim3((unsigned)(((int64_t)n_users + per_block - 1) / per_block)), \
-                           dim3(kThreads), 0, (hipStream_t)stream, gpos, part, (int)n_slices, (int64_t)n_users, U_old, \
-                           U_out, epi, adam);                                                                     \
+#define CALL(G_, NV_)                                                                                                  \
+    {                                                                                                                  \
+        constexpr int per_block = (64 / G_) * kWaves;                                                                  \
+        hipLaunchKernelGGL((k_wmrb_finish<G_, NV_, float>), dim3((unsigned)(((int64_t)n_users + per_block - 1) / per_block)), \
+                           dim3(kThreads), 0, (hipStream_t)stream, gpos, part, (int)n_slices, (int64_t)n_users, U_old,  \
+                           (void*)U_out, epi, adam);                                                                   \
     }
     TMF_DISPATCH_GEOM(geom, CALL);
 #undef CALL

@@ -50,7 +50,7 @@ class HipBackend:
     def __init__(self, st, loss, c, adam, prof=None):
         self.st, self.loss, self.c, self.adam, self.prof = st, loss, c, adam, prof
         dev = st.V.device
-        self.gV = torch.empty_like(st.V)
+        self.gV = torch.empty(st.V.shape, dtype=torch.float32, device=dev)  # raw gradient is fp32 whatever the table dtype
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
 
     def local_passes(self):
@@ -63,7 +63,7 @@ class HipBackend:
 
     def adam_rows(self, W_rows, G_rows):
         lib = _lib.get()
-        _lib.check(lib.tmf_adam_fresh_rows_f32(_lib.ptr(W_rows), _lib.ptr(G_rows), W_rows.shape[0], self.st.r,
+        _lib.check(getattr(lib, 'tmf_adam_fresh_rows' + self.st.sfx)(_lib.ptr(W_rows), _lib.ptr(G_rows), W_rows.shape[0], self.st.r,
                                                self.adam, _lib.stream_ptr()), lib)
 
     def V(self):
@@ -86,7 +86,7 @@ class DataParallelEpoch:
         if V.shape[0] % self.world:
             raise ValueError(f'V has {V.shape[0]} rows, not a multiple of world_size={self.world}')
         self.rows_per_rank = V.shape[0] // self.world
-        self.g_shard = torch.empty(self.rows_per_rank, V.shape[1], dtype=V.dtype, device=V.device)
+        self.g_shard = torch.empty(self.rows_per_rank, V.shape[1], dtype=torch.float32, device=V.device)
         self.stats = torch.zeros(2, dtype=torch.float64, device=V.device)
         self.local_count = float(local_count)
 

@@ -79,6 +79,7 @@ class MatrixFactorization:
         self.loss_history_ = []   # extension: mean loss of every epoch of the last fit
         self.fit_seconds_ = 0.0   # extension: time spent in the epoch loop of the last fit
         self.verbose = True
+        self.factor_dtype = torch.float32  # extension: torch.bfloat16 = bf16 factor storage, fp32 arithmetic
 
     # ------------------------------------------------------------------------------------------
     # training
@@ -131,7 +132,7 @@ class MatrixFactorization:
             c = self.n_items / self.n_samples  # constructor ints, true division (:167)
             wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(n_users, _lib.padded_ld(self.n_components)),
                                       item_slices=_engine.default_item_slices(n_items, _lib.padded_ld(self.n_components)))
-        st = _engine.TrainState(U0, V0, plan, self.n_components, wplan)
+        st = _engine.TrainState(U0, V0, plan, self.n_components, wplan, dtype=self.factor_dtype)
         adam = _engine.adam_constants(lr)
         loss_sums = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
         denom = plan.n_pos if wmrb else plan.nnz

@@ -372,6 +372,63 @@ def test_graph_replay_equals_eager(tm, golden, monkeypatch):
         assert m.loss_history_ == n.loss_history_ and torch.equal(m.item_embedding, n.item_embedding)
 
 
+def _bf16(x):
+    return torch.tensor(np.asarray(x, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize('r', [5, 32, 100, 256, 300, 600])
+def test_bf16_storage_one_step(tm, r):
+    """bf16 factor storage / fp32 arithmetic (BASELINE config 5, reduced size): against the fp64 closed form
+    evaluated on the bf16-rounded tables; the new rows must lie in the step interval rounded to bf16."""
+    from conftest import step_bounds
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(r)
+    m, n, S_, lr = 33, 47, 9, 0.05
+    A = (rng.random((m, n)) < 0.2) * rng.integers(-1, 6, (m, n))
+    idx, val = np.argwhere(A != 0), A[A != 0].astype(np.float32)
+    U0 = _bf16(rng.standard_normal((m, r)) * 0.3)
+    V0 = _bf16(rng.standard_normal((n, r)) * 0.3)
+    R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
+    for loss in ('mse', 'wmrb'):
+        kw = dict(user_weight_graph=tm.Fixed(U0), item_weight_graph=tm.Fixed(V0))
+        if loss == 'wmrb':
+            kw.update(loss_graph=tm.WMRB(), n_users=m, n_items=n, n_samples=S_)
+        model = tm.MF(r, **kw)
+        model.factor_dtype, model.verbose = torch.bfloat16, False
+        if loss == 'wmrb':
+            model.random_ind = torch.as_tensor(R)
+        model.fit(1, tm.eye(m), tm.eye(n), tm.Sparse(idx, val, (m, n)), lr=lr)
+        assert model.user_embedding.dtype == torch.bfloat16
+        U64, V64 = U0.astype(np.float64), V0.astype(np.float64)
+        if loss == 'mse':
+            _, _, mean, t = S.mse_epoch(U64, V64, idx, val.astype(np.float64), lr)
+        else:
+            _, _, mean, t = S.wmrb_epoch(U64, V64, idx, val.astype(np.float64), R, n, S_, lr)
+        assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+        for got, W0, g in ((model.user_embedding, U0, t['gU']), (model.item_embedding, V0, t['gV'])):
+            lo, hi = step_bounds(W0, g, lr)
+            got = got.to(torch.float32).cpu().numpy().astype(np.float64)
+            assert (got >= _bf16(lo) - 1e-12).all() and (got <= _bf16(hi) + 1e-12).all(), (loss, r)
+
+
+def test_bf16_storage_trajectory(tm, golden):
+    from oracle import sparse_ref as S
+    g = golden('wmrb_small')
+    U, V = _bf16(g['U0']), _bf16(g['V0'])
+    model = tm.MF(3, loss_graph=tm.WMRB(), n_users=50, n_items=100, n_samples=50, user_weight_graph=tm.Fixed(U),
+                  item_weight_graph=tm.Fixed(V))
+    model.factor_dtype, model.verbose, model.random_ind = torch.bfloat16, False, torch.as_tensor(g['R'])
+    model.fit(12, tm.eye(50), tm.eye(100), tm.Sparse(g['indices'], g['values'], (50, 100)), lr=0.1)
+    ref = []
+    for _ in range(12):  # oracle with the tables rounded to bf16 after every step
+        U, V, mean, _ = S.wmrb_epoch(U, V, g['indices'], g['values'], g['R'], 100, 50, 0.1)
+        U, V = _bf16(U), _bf16(V)
+        ref.append(mean)
+    assert rel_err(model.loss_history_[:2], ref[:2]) < 1e-5
+    assert rel_err(model.loss_history_, ref) < 2e-2  # bf16 rounding ties flip under fp32 reordering
+    assert float(model.recall_at_k(torch.tensor(g['A'])).mean()) > 0
+
+
 def test_wmrb_without_sample_table_raises(tm):
     model = tm.MF(3, loss_graph=tm.WMRB(), n_users=5, n_items=6)
     with pytest.raises(AttributeError):

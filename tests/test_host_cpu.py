@@ -32,6 +32,9 @@ def test_padded_ld_and_adam_constants_match_host_mirror():
         assert lib.tmf_padded_ld(r) == _lib.padded_ld(r) >= r
         assert _lib.padded_ld(r) % 4 == 0
     assert lib.tmf_padded_ld(0) == 0 and lib.tmf_padded_ld(1025) == 0
+    for r in list(range(1, 70)) + [100, 128, 129, 255, 256, 257, 512, 513, 768, 1024]:
+        assert lib.tmf_padded_ld_bf16(r) == _lib.padded_ld(r, torch.bfloat16) >= r
+        assert _lib.padded_ld(r, torch.bfloat16) % 8 == 0
     for lr in (1e-2, 1e-3, 0.1, 0.05):
         a = lib.tmf_adam_fresh(lr)
         alpha, omb1, omb2, eps = adam_fresh_constants(lr)
