@@ -204,6 +204,7 @@ def main():
     ap.add_argument('--loss', choices=['wmrb', 'mse'], default='wmrb')
     ap.add_argument('--item-dist', choices=['zipf', 'uniform'], default='zipf')
     ap.add_argument('--lr', type=float, default=0.1)
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32', help='factor storage (arithmetic is fp32 either way)')
     ap.add_argument('--small-configs', action='store_true', help='also time BASELINE configs 1-3 (GPU fit vs dense CPU restatement)')
     ap.add_argument('--no-extras', action='store_true', help='skip cpu baseline / predict / mse side measurements')
     args = ap.parse_args()
@@ -233,7 +234,9 @@ def main():
         R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
         wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r)),
                                  item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)))
-    st = _engine.TrainState(U0, V0, plan, r, wplan)
+    tdtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    sbytes = 2 if args.dtype == 'bf16' else 4
+    st = _engine.TrainState(U0, V0, plan, r, wplan, dtype=tdtype)
     adam = _engine.adam_constants(args.lr)
     c = n / S
     torch.cuda.synchronize()
@@ -285,12 +288,12 @@ def main():
 
     # dominant kernel + roofline (HIP events on the launch stream, inside the timed region)
     if args.loss == 'wmrb':
-        ub, ib = wmrb_bytes(m, n, S, plan.n_pos, r)
+        ub, ib = wmrb_bytes(m, n, S, plan.n_pos, r, sbytes)
         kname, kbytes = 'wmrb_user_pass', ub
         kms = prof.mean_ms('wmrb_user_pass')
         other = {'wmrb_item_pass_ms': prof.mean_ms('wmrb_item_pass'), 'wmrb_item_pass_alg_bytes': ib}
     else:
-        ub, ib = mse_bytes(m, n, nnz, r)
+        ub, ib = mse_bytes(m, n, nnz, r, sbytes)
         kname, kbytes = 'mse_item_pass', ib
         kms = prof.mean_ms('mse_item_pass')
         other = {'mse_user_pass_ms': prof.mean_ms('mse_user_pass'), 'mse_user_pass_alg_bytes': ub}
@@ -303,7 +306,8 @@ def main():
 
     out = dict(metric='train_interactions_per_sec', value=nnz_total / (elapsed / args.steps), unit='interactions/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
-               scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+               scaling='weak', vs_baseline=None, dtype='f32' if args.dtype == 'f32' else 'bf16 storage / f32 arithmetic',
+               data='synthetic',
                config=dict(workload=f'C4: {m} users x {n} items per GPU, r={r}, {args.loss.upper()}'
                                     + (f' S={S}' if args.loss == 'wmrb' else '') + f', item ids {args.item_dist}, '
                                     f'lognormal user degrees', interactions_per_gpu=nnz, positives_per_gpu=plan.n_pos,
@@ -317,6 +321,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline_wmrb(idx, val, R, U0, V0[:n], n, S, args.lr)
         # predict rows/s: stable top-10 over the full catalog, fused GEMM + top-k (no [m, n] matrix)
         Ue, Ve = st.U[:, :r], st.V[:n, :r]
+        if args.dtype == 'bf16':
+            Ue, Ve = Ue[:262144].float(), Ve.float()
         rows = min(m, 262144)
         _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True)
         torch.cuda.synchronize()

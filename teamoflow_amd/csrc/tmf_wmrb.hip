@@ -44,7 +44,10 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     float* c1 = BIG ? reinterpret_cast<float*>(smem_raw) : Dl + S4;  // [kPosChunk] 1 - p_k, -inf for non-positives
     float* wl = c1 + kPosChunk;                       // [kPosChunk] w_k
     float* dl = wl + kPosChunk;                       // [kPosChunk] delta_k
-    float* red = dl + kPosChunk;                      // [kWaves][LD] + 2*kWaves
+    int* ci = reinterpret_cast<int*>(dl + kPosChunk); // [kPosChunk] item of a positive entry, -1 otherwise
+    int* Rl = ci + kPosChunk;                         // [S4] the user's negatives (fused pass only): the row gathers
+                                                      //      then depend on an LDS read, not on a second global load
+    float* red = reinterpret_cast<float*>(Rl + ((SLICED || BIG) ? 0 : S4));  // [kWaves][LD] + 2*kWaves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), grp = lane / G, gid = wave * NG + grp;
@@ -69,13 +72,18 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
         // ---- phase 1 ----
         if (SLICED) {
             for (int s = tid; s < S; s += kThreads) sp[s] = sp_in[u * (int64_t)S + s];
-        } else
+        } else if (!BIG) {
+            for (int s = tid; s < S; s += kThreads) Rl[s] = Ru[s];
+            __syncthreads();
+        }
+        const int32_t* Ri = BIG ? Ru : Rl;
+        if (!SLICED)
         for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
             Frag<NV> y[kUnrollW];
 #pragma unroll
             for (int t = 0; t < kUnrollW; ++t) {
                 const int s = s0 + t * NGB;
-                if (s < S) load_row<G, NV>(y[t], V_old, Ru[s], g);
+                if (s < S) load_row<G, NV>(y[t], V_old, Ri[s], g);
                 else zero<NV>(y[t]);
             }
 #pragma unroll
@@ -96,14 +104,17 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
             const int len = (int)((re - cb < kPosChunk) ? (re - cb) : kPosChunk);
             const int len4 = round4(len);
             // 2a
+            for (int kk = tid; kk < len; kk += kThreads) ci[kk] = (val[cb + kk] > 0.f) ? col[cb + kk] : -1;
+            __syncthreads();
             for (int k0 = gid; k0 < len; k0 += NGB * kUnrollW) {
                 Frag<NV> y[kUnrollW];
                 bool pos[kUnrollW];
 #pragma unroll
                 for (int t = 0; t < kUnrollW; ++t) {
                     const int kk = k0 + t * NGB;
-                    pos[t] = (kk < len) && (val[cb + kk] > 0.f);
-                    if (pos[t]) load_row<G, NV>(y[t], V_old, col[cb + kk], g);
+                    const int item = (kk < len) ? ci[kk] : -1;
+                    pos[t] = item >= 0;
+                    if (pos[t]) load_row<G, NV>(y[t], V_old, item, g);
                     else zero<NV>(y[t]);
                 }
 #pragma unroll
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
                 for (int t = 0; t < kUnrollW; ++t) {
                     const int kk = k0 + t * NGB;
                     d[t] = (kk < len) ? dl[kk] : 0.f;
-                    if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, col[cb + kk], g);
+                    if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, ci[kk], g);
                     else zero<NV>(y[t]);
                 }
 #pragma unroll
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
             for (int t = 0; t < kUnrollW; ++t) {
                 const int s = s0 + t * NGB;
                 d[t] = (s < S) ? Dl[s] : 0.f;
-                if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, Ru[s], g);
+                if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, Ri[s], g);
                 else zero<NV>(y[t]);
             }
 #pragma unroll
@@ -232,8 +243,10 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     }
 }
 
-static size_t wmrb_user_lds(int S, int ld, bool big) {
-    return sizeof(float) * ((big ? 0 : (size_t)2 * round4(S)) + 3 * kPosChunk + (size_t)kWaves * ld + 2 * kWaves);
+static size_t wmrb_user_lds(int S, int ld, bool big, bool sliced = false) {
+    // sp + D (unless in global memory), c1 / w / delta / item per chunk entry, the user's negatives, the reduction
+    return sizeof(float) * ((big ? 0 : (size_t)2 * round4(S)) + 4 * kPosChunk +
+                            ((sliced || big) ? 0 : (size_t)round4(S)) + (size_t)kWaves * ld + 2 * kWaves);
 }
 
 template <int G, int NV, typename T, bool SLICED>
@@ -242,7 +255,7 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
                             void* U_out, float* delta, float* D, float* loss_part, float* pos_part, int epi,
                             tmf_adam adam, hipStream_t stream) {
     const bool big = wmrb_user_lds(S, 4 * G * NV, false) > 160 * 1024;
-    const size_t lds = wmrb_user_lds(S, 4 * G * NV, big);
+    const size_t lds = wmrb_user_lds(S, 4 * G * NV, big, SLICED);
     if (big) {
         if (SLICED || sp_ws == nullptr) {
             set_error("wmrb_user_pass: n_samples=%d does not fit LDS; pass the workspace of tmf_wmrb_user_workspace_bytes()", S);
