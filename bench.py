@@ -107,8 +107,8 @@ def recall_parity(dev):
 
 
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_c4_latest.json')
-PMC_KERNELS = {'wmrb_user_pass': 'tmf::k_wmrb_user<32, 1, false>', 'wmrb_item_pass': 'tmf::k_wsum_pass<32, 1>',
-               'mse_item_pass': 'tmf::k_mse_pass<32, 1>', 'mse_user_pass': 'tmf::k_mse_pass<32, 1>'}
+PMC_KERNELS = {'wmrb_user_pass': 'tmf::k_wmrb_user<32, 1, float, false, false>',
+               'wmrb_item_pass': 'tmf::k_wsum_pass<32, 1, float>'}
 
 
 def pmc_traffic(kname):
