@@ -135,6 +135,23 @@ int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t n_slices, 
                         const float* U_old, float* U_out, int n_components, int epi, tmf_adam adam,
                         void* stream);
 
+/* The same sliced pass with the hinge arithmetic overlapped inside the scores launch (default when
+ * slicing is on): one launch computes the scores slice-major over super-batches of `superbatch_users`
+ * users (0 = 65536) and, per group of 128 users, the workgroup that publishes the group's last slice runs
+ * the hinge step for those users (agent-scope release / acquire through `counters`, int32 [ceil(n_users/128)],
+ * zeroed by the call).  Then tmf_wmrb_gradu2_f32 (gradU with LDS-staged ids and D) and tmf_wmrb_finish_f32. */
+int tmf_wmrb_scores_hinge_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                              int32_t n_users, int32_t S, int32_t superbatch_users, const float* U,
+                              const float* V, float* sp, const int64_t* rowptr, const int32_t* col,
+                              const float* val, float c, float* gpos, float* delta, float* D,
+                              float* loss_part, int32_t* counters, int n_components, void* stream);
+int tmf_wmrb_scores2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                         int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
+                         int n_components, void* stream);
+int tmf_wmrb_gradu2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                        int32_t n_users, int32_t S, const float* D, const float* V, float* part,
+                        int n_components, void* stream);
+
 /* K6 standalone: W[rows] = fresh-Adam(W[rows], G[rows]) in place over n_rows x ld floats. */
 int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,
                             tmf_adam adam, void* stream);

@@ -100,29 +100,33 @@ class InteractionPlan:
         self.user_ids = u  # int64, CSR order (kept for the WMRB entry lists)
 
 
-def default_user_chunks(n_users, ld, target_bytes=8 << 20):
+def default_user_chunks(n_users, ld, target_bytes=4 << 20):
     """Number of user blocks the WMRB item lists are cut into so that the U rows the lists of one block
-    gather (n_users / chunks * ld * 4 bytes) stay cache-resident while that block is being processed.
-    Measured at C4 (1M users, 512-byte rows, item pass ms): 1 block 100.8, 8 -> 95.9, 32 -> 81.8, 64 -> 73.2,
-    128 -> 71.1, 256 -> 71.9 (profiles/r01_user_chunk_sweep.txt)."""
+    gather (n_users / chunks * ld * 4 bytes, ~one XCD L2) stay cache-resident while that block is processed.
+    Measured at C4 (1M users, 512-byte rows), item pass ms with LDS-staged entries: 32 blocks 72.0, 64 -> 57.7,
+    128 -> 42.6, 256 -> 41.6, 512 -> 54.1 (profiles/r01_user_chunk_sweep.txt)."""
     env = os.environ.get('TMF_USER_CHUNKS')
     if env:
         return max(1, int(env))
     c = -(-n_users * ld * 4 // target_bytes)
-    return int(min(max(c, 1), 128)) if c > 1 else 1
+    return int(min(max(c, 1), 256)) if c > 1 else 1
 
 
-def default_item_slices(n_items, ld):
-    """Number of item slices of the SLICED WMRB user pass; 1 = the fused single-kernel pass (default).
+def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20):
+    """Number of item slices of the sliced WMRB user pass; 1 = the fused single-kernel pass.
 
-    The sliced pass (tmf_wmrb_scores/hinge/gradu/finish) keeps every user's negatives sorted by item and
-    walks the catalog in ~4 MB slices so that V rows are gathered from the XCD L2s instead of the Infinity
-    Cache.  Measured at C4 (profiles/r01_sliced_user_pass.txt): the gathers do get faster (scores 46 ms =
-    11.7 TB/s, gradU 56 ms = 9.6 TB/s, against ~8 TB/s fused) but the hinge arithmetic, which the fused
-    kernel hides behind other workgroups' gathers, becomes a 40 ms kernel of its own: 143 ms against 140 ms
-    fused.  It therefore stays opt-in (TMF_ITEM_SLICES=n) until the hinge work is overlapped in-launch."""
+    The sliced pass keeps every user's negatives sorted by item and walks the catalog in ~4 MB slices
+    (slice-major grid) so that V rows are gathered from the XCD L2s instead of the Infinity Cache; the ids
+    (and D) of a (user, slice) range are staged in LDS so a row gather depends on an LDS read only.
+    At C4 (profiles/r01_sliced_user_pass.txt): scores 33.6 ms + hinge 25.5 ms + gradU 24.9 ms + finish = 86 ms
+    against 134 ms for the fused kernel, which is bound by the Infinity-Cache gather rate.  Used when the V table
+    is larger than two slices; small catalogs are L2-resident anyway and keep the fused kernel."""
     env = os.environ.get('TMF_ITEM_SLICES')
-    return max(1, int(env)) if env else 1
+    if env:
+        return max(1, int(env))
+    if n_items * ld * 4 <= 2 * target_bytes:
+        return 1
+    return int(min(-(-n_items * ld * 4 // target_bytes), 64))
 
 
 class WmrbPlan:
@@ -230,6 +234,7 @@ class TrainState:
             self.sp = torch.empty(m, S, dtype=torch.float32, device=dev)
             self.gpos = torch.empty(m, self.ld, dtype=torch.float32, device=dev)
             self.part = torch.empty(wplan.n_slices * m, self.ld, dtype=torch.float32, device=dev)
+            self.counters = torch.zeros((m + 127) // 128, dtype=torch.int32, device=dev)
 
     def _pad(self, W, dev):
         W = torch.as_tensor(W).detach().to(device=dev, dtype=torch.float32)
@@ -303,6 +308,28 @@ def _wmrb_user_pass_sliced(lib, st, adam, c):
     p, w, r, ld = st.plan, st.wplan, st.r, st.ld
     i32 = ctypes.c_int32
     m, S, ns = p.n_users, w.S, w.n_slices
+    mode = os.environ.get('TMF_SLICED_MODE', 'staged')
+    if mode in ('staged', 'ticket'):
+        s = _lib.stream_ptr()
+        if mode == 'ticket':
+            # one launch: scores + (last arriver per 128-user group) hinge
+            sb = int(os.environ.get('TMF_SUPERBATCH_USERS', '65536'))
+            _lib.check(lib.tmf_wmrb_scores_hinge_f32(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), i32(sb),
+                                                     _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp), _lib.ptr(p.rowptr_u),
+                                                     _lib.ptr(p.col_u), _lib.ptr(p.val_u), c, _lib.ptr(st.gpos),
+                                                     _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part),
+                                                     _lib.ptr(st.counters), r, s), lib)
+        else:
+            _lib.check(lib.tmf_wmrb_scores2_f32(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(st.U),
+                                                _lib.ptr(st.V), _lib.ptr(st.sp), r, s), lib)
+            _lib.check(lib.tmf_wmrb_hinge_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.sp),
+                                              i32(m), i32(S), c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.gpos),
+                                              _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), r, s), lib)
+        _lib.check(lib.tmf_wmrb_gradu2_f32(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(w.D),
+                                           _lib.ptr(st.V), _lib.ptr(st.part), r, s), lib)
+        _lib.check(lib.tmf_wmrb_finish_f32(_lib.ptr(st.gpos), _lib.ptr(st.part), i32(ns), i32(m), _lib.ptr(st.U),
+                                           _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s), lib)
+        return
     nb = max(1, min(int(os.environ.get('TMF_USER_BATCHES', '4')), m))
     bounds = [m * b // nb for b in range(nb + 1)]
     main = torch.cuda.current_stream()

@@ -84,58 +84,54 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weighted gather-sum pass: g[row] = sum_e wbuf[ent_w[e]] * T[ent_row[e]].  The weights of the
-// next step are fetched while the rows of the current one are in flight, because a row is only
-// loaded when its weight is non-zero (two dependent reads otherwise).
+// Weighted gather-sum pass: g[row] = sum_e wbuf[ent_w[e]] * T[ent_row[e]].  Each wave stages a tile of
+// its segment's entries (row id + gathered weight) in LDS first, so that the row gathers depend on an LDS
+// read only - the chain entry -> weight -> row would otherwise be three dependent global reads.
 // ---------------------------------------------------------------------------------------------
+constexpr int kWsumTile = 512;  // entries a wave stages in LDS per step (ids + weights: 4 KB per wave)
+
 template <int G, int NV, typename T>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
     SegView sv, const int32_t* __restrict__ ent_row, const int64_t* __restrict__ ent_w,
     const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
     void* __restrict__ X_out, float* __restrict__ slab, int epi, tmf_adam adam) {
     constexpr int NG = 64 / G;
-    const int lane = threadIdx.x & 63;
-    const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    __shared__ int s_ids[kWavesPerBlock][kWsumTile];
+    __shared__ float s_w[kWavesPerBlock][kWsumTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     if (seg >= sv.nseg) return;
     const int g = lane & (G - 1), grp = lane / G;
     const int row = sv.seg_row[seg];
     const int64_t rbeg = sv.rowptr[row], rend = sv.rowptr[row + 1];
     const int64_t beg = rbeg + (int64_t)sv.seg_chunk[seg] * sv.chunk;
     const int64_t end = (beg + sv.chunk < rend) ? beg + sv.chunk : rend;
+    int* ids = s_ids[wave];
+    float* ws = s_w[wave];
 
     Frag<NV> acc;
     zero<NV>(acc);
-
-    float w[kUnroll];
-    int src[kUnroll];
-    auto fetch = [&](int64_t k0) {
+    for (int64_t t0 = beg; t0 < end; t0 += kWsumTile) {
+        const int cnt = (int)((end - t0 < kWsumTile) ? end - t0 : kWsumTile);
+        // the wave stages the tile: coalesced entry reads, all weight gathers in flight together
+        for (int e = lane; e < cnt; e += 64) {
+            ids[e] = ent_row[t0 + e];
+            ws[e] = wbuf[ent_w[t0 + e]];
+        }
+        // lane group `grp` takes entries grp, grp + NG, ...; a row is only loaded when its weight is not 0
+        for (int e0 = grp; e0 < cnt; e0 += NG * kUnroll) {
+            Frag<NV> y[kUnroll];
+            float wc[kUnroll];
 #pragma unroll
-        for (int t = 0; t < kUnroll; ++t) {
-            const int64_t k = k0 + (int64_t)t * NG;
-            if (k < end) {
-                src[t] = ent_row[k];
-                w[t] = wbuf[ent_w[k]];
-            } else {
-                src[t] = 0;
-                w[t] = 0.f;
+            for (int t = 0; t < kUnroll; ++t) {
+                const int e = e0 + t * NG;
+                wc[t] = (e < cnt) ? ws[e] : 0.f;
+                if (wc[t] != 0.f) load_row<G, NV>(y[t], Tab, ids[e], g);
+                else zero<NV>(y[t]);
             }
-        }
-    };
-    int64_t k0 = beg + grp;
-    if (k0 < end) fetch(k0);
-    while (k0 < end) {
-        Frag<NV> y[kUnroll];
-        float wc[kUnroll];
 #pragma unroll
-        for (int t = 0; t < kUnroll; ++t) {
-            wc[t] = w[t];
-            if (wc[t] != 0.f) load_row<G, NV>(y[t], Tab, src[t], g);
-            else zero<NV>(y[t]);
+            for (int t = 0; t < kUnroll; ++t) axpy<NV>(acc, wc[t], y[t]);
         }
-        k0 += (int64_t)NG * kUnroll;
-        if (k0 < end) fetch(k0);
-#pragma unroll
-        for (int t = 0; t < kUnroll; ++t) axpy<NV>(acc, wc[t], y[t]);
     }
     across_groups_sum<G, NV>(acc);
     if (grp == 0) {

@@ -20,13 +20,19 @@ constexpr int kUnrollW = 4;
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
+// cnt += (x >= 0): compare into VCC, add it as the carry-in (2 VALU instead of cmp + cndmask + add)
+__device__ __forceinline__ void count_ge0(int& cnt, float x) {
+    asm("v_cmp_le_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(x) : "vcc");
+}
+
 // SLICED = true is the middle kernel of the sliced user pass (see k_wmrb_slice below): sp[u, :] comes from
 // global memory (sp_in) instead of phase 1, phase 3 is skipped, and the caller asks for the gradient
 // epilogue so that U_out receives only the positives' part  sum_k delta_k V[j_k].
 // BIG = true: n_samples too large for LDS - sp[u, :] and D[u, :] live in global memory (sp_ws row of
 // round4(S) floats per user, D's own row); same arithmetic, only the storage changes.
 template <int G, int NV, typename T, bool SLICED, bool BIG>
-__global__ __launch_bounds__(kThreads) void k_wmrb_user(
+__device__ __forceinline__ void wmrb_user_body(
+    const int64_t u, char* smem_raw,
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     const int32_t* __restrict__ R, const float* __restrict__ sp_in, float* __restrict__ sp_ws, int S, float c,
     const T* __restrict__ U_old,
@@ -36,9 +42,7 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     constexpr int NG = 64 / G;          // groups per wave
     constexpr int NGB = NG * kWaves;    // groups per block
     constexpr int LD = 4 * G * NV;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int S4 = round4(S);
-    const int64_t u = blockIdx.x;
     float* sp = BIG ? sp_ws + u * (int64_t)S4 : reinterpret_cast<float*>(smem_raw);   // [S4] scores, tail -inf
     float* Dl = BIG ? Dg + u * (int64_t)S : sp + S4;                                   // [S]  D[u, :]
     float* c1 = BIG ? reinterpret_cast<float*>(smem_raw) : Dl + S4;  // [kPosChunk] 1 - p_k, -inf for non-positives
@@ -47,7 +51,9 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     int* ci = reinterpret_cast<int*>(dl + kPosChunk); // [kPosChunk] item of a positive entry, -1 otherwise
     int* Rl = ci + kPosChunk;                         // [S4] the user's negatives (fused pass only): the row gathers
                                                       //      then depend on an LDS read, not on a second global load
-    float* red = reinterpret_cast<float*>(Rl + ((SLICED || BIG) ? 0 : S4));  // [kWaves][LD] + 2*kWaves
+    float* pm = reinterpret_cast<float*>(Rl + ((SLICED || BIG) ? 0 : S4));  // [kWaves][64] quarter partials of M_k
+    int* pc = reinterpret_cast<int*>(pm + kWaves * 64);                     // [kWaves][64] quarter partials of cnt_k
+    float* red = reinterpret_cast<float*>(pc + kWaves * 64);                // [kWaves][LD] + 2*kWaves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), grp = lane / G, gid = wave * NG + grp;
@@ -129,48 +135,66 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
                 wl[kk] = 0.f;
             }
             __syncthreads();
-            // 2b: one thread per interaction of the chunk
-            for (int kk = tid; kk < len; kk += kThreads) {
-                const float c1v = c1[kk];
-                float w = 0.f, d = 0.f;
-                if (c1v != -INFINITY) {
+            // 2b: hinge sums.  Tiles of 64 interactions on the lanes; wave w sweeps sample quarter w with
+            // broadcast ds_read_b128 of sp; the four quarter partials are combined in fixed order.
+            {
+                const int nf4 = S4 / 4, per_wave = (nf4 + kWaves - 1) / kWaves;
+                const int f_beg = wave * per_wave;
+                const int f_end = (f_beg + per_wave < nf4) ? f_beg + per_wave : nf4;
+                const float4* sp4 = reinterpret_cast<const float4*>(sp);
+                for (int kb = 0; kb < len; kb += 64) {
+                    const int kk = kb + lane;
+                    const float c1v = (kk < len) ? c1[kk] : -INFINITY;  // -inf: every term is 0 and never counts
                     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
                     int cnt = 0;
-                    const float4* sp4 = reinterpret_cast<const float4*>(sp);
-                    for (int s = 0; s < S4 / 4; ++s) {
-                        const float4 q = sp4[s];
+#pragma unroll 4
+                    for (int f = f_beg; f < f_end; ++f) {
+                        const float4 q = sp4[f];
                         const float x0 = c1v + q.x, x1 = c1v + q.y, x2 = c1v + q.z, x3 = c1v + q.w;
                         m0 += fmaxf(x0, 0.f);
                         m1 += fmaxf(x1, 0.f);
                         m2 += fmaxf(x2, 0.f);
                         m3 += fmaxf(x3, 0.f);
-                        cnt += (x0 >= 0.f) + (x1 >= 0.f) + (x2 >= 0.f) + (x3 >= 0.f);
+                        count_ge0(cnt, x0);
+                        count_ge0(cnt, x1);
+                        count_ge0(cnt, x2);
+                        count_ge0(cnt, x3);
                     }
-                    const float M = c * ((m0 + m1) + (m2 + m3));
-                    lsum += logf(1.0f + M);
-                    npos += 1.f;
-                    w = c * __frcp_rn(1.0f + M);
-                    d = -(w * (float)cnt);
+                    pm[wave * 64 + lane] = (m0 + m1) + (m2 + m3);
+                    pc[wave * 64 + lane] = cnt;
+                    __syncthreads();
+                    if (wave == 0 && kk < len) {
+                        float w = 0.f, d = 0.f;
+                        if (c1v != -INFINITY) {
+                            const float M = c * ((pm[lane] + pm[64 + lane]) + (pm[128 + lane] + pm[192 + lane]));
+                            const int cn = (pc[lane] + pc[64 + lane]) + (pc[128 + lane] + pc[192 + lane]);
+                            lsum += logf(1.0f + M);
+                            npos += 1.f;
+                            w = c * __frcp_rn(1.0f + M);
+                            d = -(w * (float)cn);
+                        }
+                        wl[kk] = w;
+                        dl[kk] = d;
+                        delta[cb + kk] = d;
+                    }
+                    __syncthreads();
                 }
-                wl[kk] = w;
-                dl[kk] = d;
-                delta[cb + kk] = d;
             }
-            __syncthreads();
-            // 2c: one thread per sample
+            // 2c: one thread per sample; [c1_k + sp_s >= 0] == [sp_s >= -c1_k] exactly (rounding keeps the sign)
             for (int s = tid; s < S; s += kThreads) {
                 const float sps = sp[s];
-                float dsum = 0.f;
+                float d0 = 0.f, d1 = 0.f;
                 const float4* c4 = reinterpret_cast<const float4*>(c1);
                 const float4* w4 = reinterpret_cast<const float4*>(wl);
+#pragma unroll 4
                 for (int q = 0; q < len4 / 4; ++q) {
                     const float4 cc = c4[q], ww = w4[q];
-                    dsum += (cc.x + sps >= 0.f) ? ww.x : 0.f;
-                    dsum += (cc.y + sps >= 0.f) ? ww.y : 0.f;
-                    dsum += (cc.z + sps >= 0.f) ? ww.z : 0.f;
-                    dsum += (cc.w + sps >= 0.f) ? ww.w : 0.f;
+                    d0 += (sps >= -cc.x) ? ww.x : 0.f;
+                    d1 += (sps >= -cc.y) ? ww.y : 0.f;
+                    d0 += (sps >= -cc.z) ? ww.z : 0.f;
+                    d1 += (sps >= -cc.w) ? ww.w : 0.f;
                 }
-                Dl[s] += dsum;
+                Dl[s] += d0 + d1;
             }
             // 2d
             for (int k0 = gid; k0 < len; k0 += NGB * kUnrollW) {
@@ -243,10 +267,21 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     }
 }
 
+template <int G, int NV, typename T, bool SLICED, bool BIG>
+__global__ __launch_bounds__(kThreads) void k_wmrb_user(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const int32_t* __restrict__ R, const float* __restrict__ sp_in, float* __restrict__ sp_ws, int S, float c,
+    const T* __restrict__ U_old, const T* __restrict__ V_old, void* __restrict__ U_out, float* __restrict__ delta,
+    float* __restrict__ Dg, float* __restrict__ loss_part, float* __restrict__ pos_part, int epi, tmf_adam adam) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    wmrb_user_body<G, NV, T, SLICED, BIG>(blockIdx.x, smem_raw, rowptr, col, val, R, sp_in, sp_ws, S, c, U_old, V_old, U_out,
+                                          delta, Dg, loss_part, pos_part, epi, adam);
+}
+
 static size_t wmrb_user_lds(int S, int ld, bool big, bool sliced = false) {
     // sp + D (unless in global memory), c1 / w / delta / item per chunk entry, the user's negatives, the reduction
     return sizeof(float) * ((big ? 0 : (size_t)2 * round4(S)) + 4 * kPosChunk +
-                            ((sliced || big) ? 0 : (size_t)round4(S)) + (size_t)kWaves * ld + 2 * kWaves);
+                            ((sliced || big) ? 0 : (size_t)round4(S)) + 2 * kWaves * 64 + (size_t)kWaves * ld + 2 * kWaves);
 }
 
 template <int G, int NV, typename T, bool SLICED>
@@ -335,6 +370,144 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_slice(
         }
         if (GRADU) store_row_f32<G, NV, T>(acc, part, sl * n_users + u, g);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sliced pass, in-launch overlap (TMF_ITEM_SLICES > 1, default form).  k_wmrb_scores_hinge = the scores
+// role of k_wmrb_slice + the hinge kernel, in ONE launch: users are walked in super-batches, slice-major
+// inside a super-batch; every (slice, user-group) workgroup publishes its scores and takes a ticket on
+// the group's counter, and the workgroup that draws the last ticket runs the hinge arithmetic for the
+// group's 128 users - beside the next super-batch's gathers, which is the overlap the fused kernel gets
+// between workgroups.  Hand-off = the counter form of the agent-scope release/acquire recipe
+// (cdna_hip_programming.md §6 Guideline 16): stores -> every wave's vmcnt(0) -> barrier -> lane 0 release
+// fence -> vmcnt(0) -> relaxed agent fetch_add; last arriver: acquire fence -> vmcnt(0) -> barrier -> plain
+// loads.  Counters are zeroed by a memset node before every launch.  Placement-independent.
+// Both slice roles stage the (user, slice) range's item ids (and D) through LDS so that a row gather
+// depends on an LDS read only.
+// ---------------------------------------------------------------------------------------------
+template <int G>
+struct Stage {
+    static constexpr int tile = 8 * G;  // entries staged per lane group and step: 16 KB of LDS per workgroup for every G
+};
+
+template <int G>
+__device__ __forceinline__ int* slice_stage(char* smem_raw, int gid) {
+    return reinterpret_cast<int*>(smem_raw) + gid * 2 * Stage<G>::tile;  // [ids | D] per lane group
+}
+
+template <int G, int NV, typename T, bool GRADU>
+__device__ __forceinline__ void wmrb_slice_body(
+    char* smem_raw, const int64_t sl, const int64_t ubeg, const int64_t uend, const int32_t* __restrict__ R,
+    const int32_t* __restrict__ off, int n_slices, int64_t part_users, int64_t part_u0, int S,
+    const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp, const float* __restrict__ D,
+    float* __restrict__ part) {
+    constexpr int NG = 64 / G, NGB = NG * kWaves, kStageTile = Stage<G>::tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane & (G - 1), gid = wave * NG + lane / G;
+    int* ids = slice_stage<G>(smem_raw, gid);
+    float* dst = reinterpret_cast<float*>(ids + kStageTile);
+    for (int64_t u = ubeg + gid; u < uend; u += NGB) {
+        const int beg = off[u * (n_slices + 1) + sl], end = off[u * (n_slices + 1) + sl + 1];
+        const int32_t* Ru = R + u * (int64_t)S;
+        Frag<NV> x, acc;
+        if (GRADU) zero<NV>(acc);
+        else load_row<G, NV>(x, U, u, g);
+        for (int t0 = beg; t0 < end; t0 += kStageTile) {
+            const int cnt = (end - t0 < kStageTile) ? end - t0 : kStageTile;
+            for (int e = g; e < cnt; e += G) {
+                ids[e] = Ru[t0 + e];
+                if (GRADU) dst[e] = D[u * (int64_t)S + t0 + e];
+            }
+            for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
+                Frag<NV> y[kUnrollW];
+                float d[kUnrollW];
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) {
+                    const int e = e0 + t;
+                    bool want = e < cnt;
+                    d[t] = 0.f;
+                    if (GRADU && want) { d[t] = dst[e]; want = d[t] != 0.f; }
+                    if (want) load_row<G, NV>(y[t], V, ids[e], g);
+                    else zero<NV>(y[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) {
+                    if (GRADU) {
+                        axpy<NV>(acc, d[t], y[t]);
+                    } else {
+                        const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
+                        if (g == 0 && e0 + t < cnt) sp[u * (int64_t)S + t0 + e0 + t] = p;
+                    }
+                }
+            }
+        }
+        if (GRADU) store_row_f32<G, NV, T>(acc, part, sl * part_users + (u - part_u0), g);
+    }
+}
+
+// grid = n_superbatches * n_slices * groups_per_sb; block -> (super-batch, slice, group in super-batch)
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(kThreads) void k_wmrb_scores_hinge(
+    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
+    int64_t groups_per_sb, int64_t n_groups, const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp,
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, float c,
+    float* __restrict__ gpos, float* __restrict__ delta, float* __restrict__ Dg, float* __restrict__ loss_part,
+    int* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t per_sb = groups_per_sb * n_slices;
+    const int64_t sb = blockIdx.x / per_sb, rem = blockIdx.x % per_sb;
+    const int64_t sl = rem / groups_per_sb, grp = sb * groups_per_sb + rem % groups_per_sb;
+    if (grp >= n_groups) return;  // block-uniform
+    const int64_t ubeg = grp * kSliceUsers;
+    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
+    wmrb_slice_body<G, NV, T, false>(smem_raw, sl, ubeg, uend, R, off, n_slices, 0, 0, S, U, V, sp, nullptr, nullptr);
+
+    // publish this block's scores and take a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem_raw);
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flag[0] = __hip_atomic_fetch_add(&counters[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool last = flag[0] == n_slices - 1;  // block-uniform
+    __syncthreads();                            // everyone has read the flag before LDS is reused
+    if (!last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const tmf_adam none = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t u = ubeg; u < uend; ++u) {
+        wmrb_user_body<G, NV, T, true, false>(u, smem_raw, rowptr, col, val, nullptr, sp, nullptr, S, c, U, V, gpos, delta, Dg,
+                                              loss_part, nullptr, TMF_EPI_GRAD, none);
+        __syncthreads();
+    }
+}
+
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(kThreads) void k_wmrb_scores2(
+    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
+    int64_t n_groups, const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t sl = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    const int64_t ubeg = grp * kSliceUsers;
+    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
+    wmrb_slice_body<G, NV, T, false>(smem_raw, sl, ubeg, uend, R, off, n_slices, 0, 0, S, U, V, sp, nullptr, nullptr);
+}
+
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(kThreads) void k_wmrb_gradu2(
+    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
+    int64_t n_groups, const T* __restrict__ V, const float* __restrict__ D, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t sl = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    const int64_t ubeg = grp * kSliceUsers;
+    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
+    wmrb_slice_body<G, NV, T, true>(smem_raw, sl, ubeg, uend, R, off, n_slices, n_users, 0, S, nullptr, V, nullptr, D, part);
 }
 
 template <int G, int NV, typename T>
@@ -469,4 +642,71 @@ extern "C" int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t
     TMF_DISPATCH_GEOM(geom, CALL);
 #undef CALL
     return check_launch("tmf_wmrb_finish_f32");
+}
+
+extern "C" int tmf_wmrb_scores_hinge_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                                         int32_t n_users, int32_t S, int32_t superbatch_users, const float* U,
+                                         const float* V, float* sp, const int64_t* rowptr, const int32_t* col,
+                                         const float* val, float c, float* gpos, float* delta, float* D,
+                                         float* loss_part, int32_t* counters, int n_components, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(R_sorted && slice_off && U && V && sp && rowptr && gpos && D && counters && n_slices > 0 && S > 0,
+                "wmrb_scores_hinge: bad arguments");
+    const RowGeom geom = row_geom(n_components);
+    const int64_t n_groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
+    int64_t gps = ((int64_t)(superbatch_users > 0 ? superbatch_users : 65536) + kSliceUsers - 1) / kSliceUsers;
+    if (gps > n_groups) gps = n_groups;
+    const int64_t n_sb = (n_groups + gps - 1) / gps;
+    const int64_t blocks = n_sb * gps * n_slices;
+    TMF_REQUIRE(blocks < ((int64_t)1 << 31), "wmrb_scores_hinge: grid too large");
+    size_t lds = wmrb_user_lds(S, geom.ld, false, true);
+    const size_t stage = (size_t)(64 / geom.G) * kWaves * 2 * 8 * geom.G * sizeof(int);
+    if (stage > lds) lds = stage;
+    if (lds > 64 * 1024) {
+        set_error("wmrb_scores_hinge: n_samples=%d needs %zu bytes of LDS; use the fused pass", S, lds);
+        return TMF_E_UNSUPPORTED;
+    }
+    hipError_t e = hipMemsetAsync(counters, 0, (size_t)n_groups * sizeof(int32_t), (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return TMF_E_LAUNCH; }
+#define CALL(G_, NV_)                                                                                                \
+    hipLaunchKernelGGL((k_wmrb_scores_hinge<G_, NV_, float>), dim3((unsigned)blocks), dim3(kThreads), lds,            \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, gps, n_groups, U, \
+                       V, sp, rowptr, col, val, c, gpos, delta, D, loss_part, counters)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_scores_hinge_f32");
+}
+
+extern "C" int tmf_wmrb_gradu2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                                   int32_t n_users, int32_t S, const float* D, const float* V, float* part,
+                                   int n_components, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(R_sorted && slice_off && D && V && part && n_slices > 0 && S > 0, "wmrb_gradu2: bad arguments");
+    const RowGeom geom = row_geom(n_components);
+    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
+    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_gradu2: grid too large");
+    const size_t lds = (size_t)(64 / geom.G) * kWaves * 2 * 8 * geom.G * sizeof(int);
+#define CALL(G_, NV_)                                                                                               \
+    hipLaunchKernelGGL((k_wmrb_gradu2<G_, NV_, float>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, V, D, part)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_gradu2_f32");
+}
+
+extern "C" int tmf_wmrb_scores2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                                    int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
+                                    int n_components, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(R_sorted && slice_off && U && V && sp && n_slices > 0 && S > 0, "wmrb_scores2: bad arguments");
+    const RowGeom geom = row_geom(n_components);
+    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
+    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_scores2: grid too large");
+    const size_t lds = (size_t)(64 / geom.G) * kWaves * 2 * 8 * geom.G * sizeof(int);
+#define CALL(G_, NV_)                                                                                                \
+    hipLaunchKernelGGL((k_wmrb_scores2<G_, NV_, float>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, U, V, sp)
+    TMF_DISPATCH_GEOM(geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_scores2_f32");
 }

@@ -219,10 +219,14 @@ def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
     assert rel_err(chunked.loss_history_, base.loss_history_) < 1e-6
 
 
+@pytest.mark.parametrize('mode', ['staged', 'ticket', 'v1'])
 @pytest.mark.parametrize('slices', ['2', '5', '64'])
-def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices):
-    """TMF_ITEM_SLICES > 1: scores / hinge / gradU / finish kernels instead of the fused user pass."""
+def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, mode):
+    """TMF_ITEM_SLICES > 1: the sliced user pass instead of the fused one - scores+hinge in one launch with the
+    last-arriver hand-off (default) or the four separate kernels (TMF_SLICED_V1)."""
     monkeypatch.setenv('TMF_ITEM_SLICES', slices)
+    monkeypatch.setenv('TMF_SUPERBATCH_USERS', '256')
+    monkeypatch.setenv('TMF_SLICED_MODE', mode)
     for name in ('wmrb_small', 'wmrb_mixed'):
         g = golden(name)
         model, t = check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, float(g['lr']), 'wmrb',
