@@ -289,9 +289,18 @@ def main():
     # dominant kernel + roofline (HIP events on the launch stream, inside the timed region)
     if args.loss == 'wmrb':
         ub, ib = wmrb_bytes(m, n, S, plan.n_pos, r, sbytes)
-        kname, kbytes = 'wmrb_user_pass', ub
-        kms = prof.mean_ms('wmrb_user_pass')
-        other = {'wmrb_item_pass_ms': prof.mean_ms('wmrb_item_pass'), 'wmrb_item_pass_alg_bytes': ib}
+        ums, ims = prof.mean_ms('wmrb_user_pass'), prof.mean_ms('wmrb_item_pass')
+        sliced = wplan.n_slices > 1
+        # dominant single kernel: the fused user pass, or (sliced user pass = 4 kernels) the item gather-sum
+        if not sliced and ums >= ims:
+            kname, kbytes, kms = 'wmrb_user_pass', ub, ums
+        else:
+            kname, kbytes, kms = 'wmrb_item_pass', ib, ims
+        other = {'wmrb_user_pass_ms': ums, 'wmrb_user_pass_alg_bytes': ub, 'wmrb_item_pass_ms': ims,
+                 'wmrb_item_pass_alg_bytes': ib,
+                 'wmrb_user_pass_form': (f'sliced: scores + hinge + gradU + finish kernels over {wplan.n_slices} item slices'
+                                         if sliced else 'fused single kernel'),
+                 'wmrb_item_lists_user_blocks': wplan.user_chunks}
     else:
         ub, ib = mse_bytes(m, n, nnz, r, sbytes)
         kname, kbytes = 'mse_item_pass', ib
@@ -302,6 +311,7 @@ def main():
     roofline = dict(bound='hbm', kernel=kname, achieved=achieved, peak=HBM_PEAK / 1e9, unit='GB/s',
                     frac=achieved / (HBM_PEAK / 1e9), traffic=traffic, traffic_source=traffic_src, kernel_ms=kms,
                     alg_bytes_per_launch=kbytes,
+                    note='achieved counts ALGORITHMIC bytes (SURVEY 8d); gathers served by L2 / Infinity Cache let it exceed the HBM peak',
                     epoch_alg_bytes=ub + ib, epoch_frac=(ub + ib) / (ms_per_step * 1e-3) / HBM_PEAK, **other)
 
     out = dict(metric='train_interactions_per_sec', value=nnz_total / (elapsed / args.steps), unit='interactions/s',
