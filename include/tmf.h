@@ -115,42 +115,54 @@ size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int n_component
 /* Sliced form of the same user pass for catalogs whose V table is larger than the L2s (speed only - the
  * results obey the same contract).  R_sorted [n_users, S] holds every user's negatives in ascending item
  * order; slice_off [n_users, n_slices + 1] int32 gives, per user, the first sample of every item slice
- * (slice_off[u][0] = 0, slice_off[u][n_slices] = S).  Call in this order on one stream:
- *   tmf_wmrb_scores_f32  sp[u, s] = <U[u], V[R_sorted[u, s]]>                      (slice-major grid)
- *   tmf_wmrb_hinge_f32   delta, D (in R_sorted order), loss_part, gpos[u] = sum_k delta_k V[j_k]
- *   tmf_wmrb_gradu_f32   part[slice][u] = sum_{s in slice} D[u, s] V[R_sorted[u, s]]  (slice-major grid)
- *   tmf_wmrb_finish_f32  U_out[u] = epilogue(gpos[u] + sum_slice part[slice][u])
- * sp [n_users, S], gpos [n_users, ld], part [n_slices * n_users, ld] are caller-provided scratch. */
-int tmf_wmrb_scores_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                        int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
-                        int n_components, void* stream);
-int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
-                       int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
-                       float* gpos, float* delta, float* D, float* loss_part, int n_components,
-                       void* stream);
-int tmf_wmrb_gradu_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                       int32_t n_users, int32_t S, const float* D, const float* V, float* part,
-                       int n_components, void* stream);
-int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
-                        const float* U_old, float* U_out, int n_components, int epi, tmf_adam adam,
-                        void* stream);
+ * (slice_off[u][0] = 0, slice_off[u][n_slices] = S).  Kernels, called in this order on one stream:
+ *   tmf_wmrb_scores2_*  sp[u, s] = <U[u], V[R_sorted[u, s]]>                       (slice-major grid)
+ *   tmf_wmrb_hinge_*    delta, D (in R_sorted order), loss_part, gpos[u] = sum_k delta_k V[j_k]
+ *   tmf_wmrb_gradu2_*   part[slice][u] = sum_{s in slice} D[u, s] V[R_sorted[u, s]]   (slice-major grid)
+ *   tmf_wmrb_finish_*   U_out[u] = epilogue(gpos[u] + sum_slice part[slice][u])
+ * sp [n_users, S], gpos [n_users, ld], part are caller-provided fp32 scratch. */
 
-/* The same sliced pass with the hinge arithmetic overlapped inside the scores launch (default when
- * slicing is on): one launch computes the scores slice-major over super-batches of `superbatch_users`
+/* Experiment: the hinge arithmetic overlapped inside the scores launch: one launch computes the scores slice-major over super-batches of `superbatch_users`
  * users (0 = 65536) and, per group of 128 users, the workgroup that publishes the group's last slice runs
  * the hinge step for those users (agent-scope release / acquire through `counters`, int32 [ceil(n_users/128)],
- * zeroed by the call).  Then tmf_wmrb_gradu2_f32 (gradU with LDS-staged ids and D) and tmf_wmrb_finish_f32. */
+ * zeroed by the call).  Then tmf_wmrb_gradu2_f32 and tmf_wmrb_finish_f32.  Slower than the separate kernels at C4
+ * (too few hinge executors in flight), kept for the record. */
 int tmf_wmrb_scores_hinge_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
                               int32_t n_users, int32_t S, int32_t superbatch_users, const float* U,
                               const float* V, float* sp, const int64_t* rowptr, const int32_t* col,
                               const float* val, float c, float* gpos, float* delta, float* D,
                               float* loss_part, int32_t* counters, int n_components, void* stream);
+/* Staged sliced pass (the default for catalogs larger than two slices) - tables are float (_f32) or bf16
+ * (_bf16) rows, passed as void*; sp / gpos / part / D / delta stay fp32.
+ * gradu2: per_slice_launches = 0 -> one launch, part is [n_slices * n_users, ld] and finish gets n_slices;
+ *         per_slice_launches = 1 -> one launch per slice adding into a single [n_users, ld] layer (memory-light:
+ *         finish is then called with n_slices = 1). */
 int tmf_wmrb_scores2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                         int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
-                         int n_components, void* stream);
+                          int32_t n_users, int32_t S, const void* U, const void* V, float* sp,
+                          int n_components, void* stream);
+int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
+                        int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old,
+                        float* gpos, float* delta, float* D, float* loss_part, int n_components,
+                        void* stream);
 int tmf_wmrb_gradu2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                        int32_t n_users, int32_t S, const float* D, const float* V, float* part,
-                        int n_components, void* stream);
+                         int32_t n_users, int32_t S, const float* D, const void* V, float* part,
+                         int per_slice_launches, int n_components, void* stream);
+int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
+                         const void* U_old, void* U_out, int n_components, int epi, tmf_adam adam,
+                         void* stream);
+int tmf_wmrb_scores2_bf16(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                          int32_t n_users, int32_t S, const void* U, const void* V, float* sp,
+                          int n_components, void* stream);
+int tmf_wmrb_hinge_bf16(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
+                        int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old,
+                        float* gpos, float* delta, float* D, float* loss_part, int n_components,
+                        void* stream);
+int tmf_wmrb_gradu2_bf16(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
+                         int32_t n_users, int32_t S, const float* D, const void* V, float* part,
+                         int per_slice_launches, int n_components, void* stream);
+int tmf_wmrb_finish_bf16(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
+                         const void* U_old, void* U_out, int n_components, int epi, tmf_adam adam,
+                         void* stream);
 
 /* K6 standalone: W[rows] = fresh-Adam(W[rows], G[rows]) in place over n_rows x ld floats. */
 int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 DEFAULT_CHUNK = 1024  # list entries per segment (heavy rows are cut into several segments)
+PART_BUDGET = int(os.environ.get('TMF_PART_BUDGET', 1 << 30))  # bytes of gradU slice partials kept before summing in place
 
 
 def _excl_cumsum(x):
@@ -100,7 +101,10 @@ class InteractionPlan:
         self.user_ids = u  # int64, CSR order (kept for the WMRB entry lists)
 
 
-def default_user_chunks(n_users, ld, target_bytes=4 << 20):
+SLAB_BUDGET = int(os.environ.get('TMF_SLAB_BUDGET', 8 << 30))  # bytes of per-(user block, item) partial rows
+
+
+def default_user_chunks(n_users, ld, target_bytes=4 << 20, n_items=None):
     """Number of user blocks the WMRB item lists are cut into so that the U rows the lists of one block
     gather (n_users / chunks * ld * 4 bytes, ~one XCD L2) stay cache-resident while that block is processed.
     Measured at C4 (1M users, 512-byte rows), item pass ms with LDS-staged entries: 32 blocks 72.0, 64 -> 57.7,
@@ -109,6 +113,8 @@ def default_user_chunks(n_users, ld, target_bytes=4 << 20):
     if env:
         return max(1, int(env))
     c = -(-n_users * ld * 4 // target_bytes)
+    if n_items:  # every (block, item) list owns at least one fp32 partial row: keep that slab within budget
+        c = min(c, max(1, SLAB_BUDGET // (n_items * ld * 4)))
     return int(min(max(c, 1), 256)) if c > 1 else 1
 
 
@@ -209,8 +215,6 @@ class TrainState:
         self.r = int(n_components)
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError('factor tables are stored as float32 or bfloat16')
-        if dtype is torch.bfloat16 and wplan is not None and wplan.n_slices > 1:
-            raise ValueError('the sliced WMRB user pass is fp32 only')
         self.dtype = dtype
         self.sfx = '_bf16' if dtype is torch.bfloat16 else '_f32'
         self.ld = _lib.padded_ld(self.r, dtype)
@@ -219,7 +223,6 @@ class TrainState:
         self.U_nxt = torch.empty_like(self.U)
         self.V_nxt = torch.empty_like(self.V)
         self.plan, self.wplan = plan, wplan
-        self.side_streams = None
         n_slab = max(plan.seg_u.n_slab, plan.seg_i.n_slab, wplan.seg_e.n_slab if wplan else 0, 1)
         self.slab = torch.empty(n_slab, self.ld, dtype=torch.float32, device=dev)
         n_part = max(plan.seg_u.nseg, plan.n_users, 1)
@@ -232,8 +235,10 @@ class TrainState:
         if wplan is not None and wplan.n_slices > 1:
             m, S = wplan.R.shape
             self.sp = torch.empty(m, S, dtype=torch.float32, device=dev)
-            self.gpos = torch.empty(m, self.ld, dtype=torch.float32, device=dev)
-            self.part = torch.empty(wplan.n_slices * m, self.ld, dtype=torch.float32, device=dev)
+            self.gpos = torch.empty(m, self.ld, dtype=torch.float32, device=dev)  # fp32 whatever the table dtype
+            # gradU partials: one layer per slice, or (above PART_BUDGET bytes) a single layer summed by per-slice launches
+            self.part_layers = wplan.n_slices if wplan.n_slices * m * self.ld * 4 <= PART_BUDGET else 1
+            self.part = torch.empty(self.part_layers * m, self.ld, dtype=torch.float32, device=dev)
             self.counters = torch.zeros((m + 127) // 128, dtype=torch.int32, device=dev)
 
     def _pad(self, W, dev):
@@ -302,13 +307,13 @@ def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=No
 
 
 def _wmrb_user_pass_sliced(lib, st, adam, c):
-    """scores -> hinge -> gradU -> finish over batches of users, alternating between two side streams so
-    that the VALU-bound hinge kernel of one batch runs beside the memory-bound slice kernels of the next
-    (in the fused kernel that overlap happens between workgroups of one launch)."""
+    """Sliced user pass: scores -> hinge -> gradU -> finish (see csrc/tmf_wmrb.hip)."""
     p, w, r, ld = st.plan, st.wplan, st.r, st.ld
     i32 = ctypes.c_int32
     m, S, ns = p.n_users, w.S, w.n_slices
     mode = os.environ.get('TMF_SLICED_MODE', 'staged')
+    if st.dtype is not torch.float32 and mode != 'staged':
+        raise ValueError('only the staged sliced pass supports bf16 tables')
     if mode in ('staged', 'ticket'):
         s = _lib.stream_ptr()
         if mode == 'ticket':
@@ -320,47 +325,17 @@ def _wmrb_user_pass_sliced(lib, st, adam, c):
                                                      _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part),
                                                      _lib.ptr(st.counters), r, s), lib)
         else:
-            _lib.check(lib.tmf_wmrb_scores2_f32(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(st.U),
+            _lib.check(getattr(lib, 'tmf_wmrb_scores2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(st.U),
                                                 _lib.ptr(st.V), _lib.ptr(st.sp), r, s), lib)
-            _lib.check(lib.tmf_wmrb_hinge_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.sp),
+            _lib.check(getattr(lib, 'tmf_wmrb_hinge' + st.sfx)(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.sp),
                                               i32(m), i32(S), c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.gpos),
                                               _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), r, s), lib)
-        _lib.check(lib.tmf_wmrb_gradu2_f32(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(w.D),
-                                           _lib.ptr(st.V), _lib.ptr(st.part), r, s), lib)
-        _lib.check(lib.tmf_wmrb_finish_f32(_lib.ptr(st.gpos), _lib.ptr(st.part), i32(ns), i32(m), _lib.ptr(st.U),
-                                           _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s), lib)
+        _lib.check(getattr(lib, 'tmf_wmrb_gradu2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(w.D),
+                                           _lib.ptr(st.V), _lib.ptr(st.part), int(st.part_layers == 1 and ns > 1), r, s), lib)
+        _lib.check(getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.gpos), _lib.ptr(st.part), i32(st.part_layers), i32(m),
+                                                            _lib.ptr(st.U), _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s), lib)
         return
-    nb = max(1, min(int(os.environ.get('TMF_USER_BATCHES', '4')), m))
-    bounds = [m * b // nb for b in range(nb + 1)]
-    main = torch.cuda.current_stream()
-    if st.side_streams is None:
-        st.side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    streams = st.side_streams if nb > 1 else [main]
-    for sd in streams:
-        if sd is not main:
-            sd.wait_stream(main)
-
-    def at(t, row):  # device pointer of row `row` of a 2-D tensor (or element of a 1-D one)
-        return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
-
-    for b in range(nb):
-        b0, n_b = bounds[b], bounds[b + 1] - bounds[b]
-        if n_b == 0:
-            continue
-        with torch.cuda.stream(streams[b % len(streams)]):
-            sp = _lib.stream_ptr()
-            _lib.check(lib.tmf_wmrb_scores_f32(at(w.R, b0), at(w.slice_off, b0), i32(ns), i32(n_b), i32(S), at(st.U, b0),
-                                               _lib.ptr(st.V), at(st.sp, b0), r, sp), lib)
-            _lib.check(lib.tmf_wmrb_hinge_f32(at(p.rowptr_u, b0), _lib.ptr(p.col_u), _lib.ptr(p.val_u), at(st.sp, b0),
-                                              i32(n_b), i32(S), c, at(st.U, b0), _lib.ptr(st.V), at(st.gpos, b0),
-                                              _lib.ptr(w.delta), at(w.D, b0), at(st.loss_part, b0), r, sp), lib)
-            _lib.check(lib.tmf_wmrb_gradu_f32(at(w.R, b0), at(w.slice_off, b0), i32(ns), i32(n_b), i32(S), at(w.D, b0),
-                                              _lib.ptr(st.V), at(st.part, ns * b0), r, sp), lib)
-            _lib.check(lib.tmf_wmrb_finish_f32(at(st.gpos, b0), at(st.part, ns * b0), i32(ns), i32(n_b), at(st.U, b0),
-                                               at(st.U_nxt, b0), r, _lib.EPI_ADAM, adam, sp), lib)
-    for sd in streams:
-        if sd is not main:
-            main.wait_stream(sd)
+    raise ValueError(f'unknown TMF_SLICED_MODE={mode!r}')
 
 
 def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):

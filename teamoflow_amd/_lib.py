@@ -38,7 +38,8 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _SEG = ctypes.POINTER(Segments)
 
 # name -> (restype, argtypes); must list every symbol include/tmf.h declares (tests check this)
-SIGNATURES = {
+SIGNATURES = {}
+_BASE_SIGNATURES = {
     'tmf_version': (_I, []),
     'tmf_last_error': (ctypes.c_char_p, []),
     'tmf_padded_ld': (_I, [_I]),
@@ -50,14 +51,12 @@ SIGNATURES = {
     'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _I, _I, Adam, _P]),
     'tmf_wmrb_user_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, _I]),
-    'tmf_wmrb_scores_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
     'tmf_wmrb_hinge_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
-    'tmf_wmrb_gradu_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
     'tmf_wmrb_finish_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_scores_hinge_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P,
                                         _P, _F, _P, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_scores2_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
-    'tmf_wmrb_gradu2_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
+    'tmf_wmrb_gradu2_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _I, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
     'tmf_mse_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
@@ -71,6 +70,10 @@ SIGNATURES = {
     'tmf_topk_stable_f32': (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
     'tmf_predict_topk_f32': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P]),
 }
+
+SIGNATURES.update(_BASE_SIGNATURES)
+for _name in ('tmf_wmrb_scores2', 'tmf_wmrb_hinge', 'tmf_wmrb_gradu2', 'tmf_wmrb_finish'):
+    SIGNATURES[_name + '_bf16'] = SIGNATURES[_name + '_f32']
 
 _lib = None
 

@@ -321,60 +321,16 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 // sorted by item id and the catalog is cut into slices of ~2-4 MB of V rows; blocks are numbered
 // slice-major, so the workgroups resident at any moment gather from ONE slice, which the XCD L2s hold
 // (13-14 TB/s measured for the same gather, profiles/r01_user_chunk_sweep.txt).  Three kernels:
-//   k_wmrb_slice<SCORES>  sp[u, s]  = <U[u], V[R[u, s]]>            for s in the slice      -> global
+//   k_wmrb_scores2        sp[u, s]  = <U[u], V[R[u, s]]>            for s in the slice      -> global
 //   k_wmrb_user<SLICED>   hinge math on sp (+ positives): delta, D, loss, gpos[u] = sum_k delta_k V[j_k]
-//   k_wmrb_slice<GRADU>   part[slice][u] = sum_{s in slice} D[u, s] V[R[u, s]]              -> global
+//   k_wmrb_gradu2         part[slice][u] = sum_{s in slice} D[u, s] V[R[u, s]]              -> global
 //   k_wmrb_finish         gU[u] = gpos[u] + sum_slice part[slice][u] (fixed order) -> epilogue
 // Block placement is used for speed only; any dispatch order gives the same bits.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSliceUsers = 128;  // users per workgroup of k_wmrb_slice
 
-template <int G, int NV, typename T, bool GRADU>
-__global__ __launch_bounds__(kThreads) void k_wmrb_slice(
-    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
-    int64_t n_groups, const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp,
-    const float* __restrict__ D, float* __restrict__ part) {
-    constexpr int NG = 64 / G, NGB = NG * kWaves;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane & (G - 1), gid = wave * NG + lane / G;
-    const int64_t sl = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
-    const int64_t ubeg = grp * kSliceUsers;
-    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
-    for (int64_t u = ubeg + gid; u < uend; u += NGB) {
-        const int beg = off[u * (n_slices + 1) + sl], end = off[u * (n_slices + 1) + sl + 1];
-        const int32_t* Ru = R + u * (int64_t)S;
-        Frag<NV> x, acc;
-        if (GRADU) zero<NV>(acc);
-        else load_row<G, NV>(x, U, u, g);
-        for (int s0 = beg; s0 < end; s0 += kUnrollW) {
-            Frag<NV> y[kUnrollW];
-            float d[kUnrollW];
-#pragma unroll
-            for (int t = 0; t < kUnrollW; ++t) {
-                const int s = s0 + t;
-                d[t] = 0.f;
-                bool want = s < end;
-                if (GRADU && want) { d[t] = D[u * (int64_t)S + s]; want = d[t] != 0.f; }
-                if (want) load_row<G, NV>(y[t], V, Ru[s], g);
-                else zero<NV>(y[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < kUnrollW; ++t) {
-                if (GRADU) {
-                    axpy<NV>(acc, d[t], y[t]);
-                } else {
-                    const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
-                    if (g == 0 && s0 + t < end) sp[u * (int64_t)S + s0 + t] = p;
-                }
-            }
-        }
-        if (GRADU) store_row_f32<G, NV, T>(acc, part, sl * n_users + u, g);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Sliced pass, in-launch overlap (TMF_ITEM_SLICES > 1, default form).  k_wmrb_scores_hinge = the scores
-// role of k_wmrb_slice + the hinge kernel, in ONE launch: users are walked in super-batches, slice-major
+// Experiment (TMF_SLICED_MODE=ticket): k_wmrb_scores_hinge = the scores kernel + the hinge kernel in ONE launch: users are walked in super-batches, slice-major
 // inside a super-batch; every (slice, user-group) workgroup publishes its scores and takes a ticket on
 // the group's counter, and the workgroup that draws the last ticket runs the hinge arithmetic for the
 // group's 128 users - beside the next super-batch's gathers, which is the overlap the fused kernel gets
@@ -400,7 +356,7 @@ __device__ __forceinline__ void wmrb_slice_body(
     char* smem_raw, const int64_t sl, const int64_t ubeg, const int64_t uend, const int32_t* __restrict__ R,
     const int32_t* __restrict__ off, int n_slices, int64_t part_users, int64_t part_u0, int S,
     const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp, const float* __restrict__ D,
-    float* __restrict__ part) {
+    float* __restrict__ part, int accumulate = 0) {
     constexpr int NG = 64 / G, NGB = NG * kWaves, kStageTile = Stage<G>::tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
@@ -441,7 +397,19 @@ __device__ __forceinline__ void wmrb_slice_body(
                 }
             }
         }
-        if (GRADU) store_row_f32<G, NV, T>(acc, part, sl * part_users + (u - part_u0), g);
+        if (GRADU) {
+            if (accumulate == 0) {
+                store_row_f32<G, NV, T>(acc, part, sl * part_users + (u - part_u0), g);
+            } else {  // one launch per slice: part is a single [users, ld] layer summed in slice order
+                if (accumulate == 2) {
+                    Frag<NV> prev;
+                    load_row_f32<G, NV, T>(prev, part, u - part_u0, g);
+                    add<NV>(prev, acc);
+                    acc = prev;
+                }
+                store_row_f32<G, NV, T>(acc, part, u - part_u0, g);
+            }
+        }
     }
 }
 
@@ -499,15 +467,18 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_scores2(
     wmrb_slice_body<G, NV, T, false>(smem_raw, sl, ubeg, uend, R, off, n_slices, 0, 0, S, U, V, sp, nullptr, nullptr);
 }
 
+// slice_first >= 0: this launch covers ONE slice (slice_first) and adds into the single-layer `part`
+// (plain read-modify-write; launches of consecutive slices are ordered by the stream).
 template <int G, int NV, typename T>
 __global__ __launch_bounds__(kThreads) void k_wmrb_gradu2(
     const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
-    int64_t n_groups, const T* __restrict__ V, const float* __restrict__ D, float* __restrict__ part) {
+    int64_t n_groups, const T* __restrict__ V, const float* __restrict__ D, float* __restrict__ part, int slice_first) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int64_t sl = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    const int64_t sl = (slice_first >= 0) ? slice_first : blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
     const int64_t ubeg = grp * kSliceUsers;
     const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
-    wmrb_slice_body<G, NV, T, true>(smem_raw, sl, ubeg, uend, R, off, n_slices, n_users, 0, S, nullptr, V, nullptr, D, part);
+    wmrb_slice_body<G, NV, T, true>(smem_raw, sl, ubeg, uend, R, off, n_slices, n_users, 0, S, nullptr, V, nullptr, D, part,
+                                    slice_first < 0 ? 0 : (slice_first == 0 ? 1 : 2));
 }
 
 template <int G, int NV, typename T>
@@ -575,74 +546,9 @@ extern "C" int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col
                                        pos_part, workspace, n_components, epi, adam, stream);
 }
 
-extern "C" int tmf_wmrb_scores_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                                   int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
-                                   int n_components, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(R_sorted && slice_off && U && V && sp && n_slices > 0 && S > 0, "wmrb_scores: bad arguments");
-    const RowGeom geom = row_geom(n_components);
-    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
-    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_scores: grid too large");
-#define CALL(G_, NV_)                                                                                                  \
-    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, float, false>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,   \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, U, V, sp, \
-                       (const float*)nullptr, (float*)nullptr)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return check_launch("tmf_wmrb_scores_f32");
-}
 
-extern "C" int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
-                                  int32_t n_users, int32_t S, float c, const float* U_old, const float* V_old,
-                                  float* gpos, float* delta, float* D, float* loss_part, int n_components,
-                                  void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(rowptr && sp && U_old && V_old && gpos && D && n_users > 0 && S > 0, "wmrb_hinge: bad arguments");
-    const RowGeom geom = row_geom(n_components);
-    tmf_adam none = {0.f, 0.f, 0.f, 0.f};
-#define CALL(G_, NV_)                                                                                                   \
-    return launch_wmrb_user<G_, NV_, float, true>(rowptr, col, val, nullptr, sp, nullptr, n_users, S, c, U_old, V_old, gpos, \
-                                                  delta, D, loss_part, nullptr, TMF_EPI_GRAD, none, (hipStream_t)stream)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return TMF_OK;
-}
 
-extern "C" int tmf_wmrb_gradu_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                                  int32_t n_users, int32_t S, const float* D, const float* V, float* part,
-                                  int n_components, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(R_sorted && slice_off && D && V && part && n_slices > 0 && S > 0, "wmrb_gradu: bad arguments");
-    const RowGeom geom = row_geom(n_components);
-    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
-    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_gradu: grid too large");
-#define CALL(G_, NV_)                                                                                                 \
-    hipLaunchKernelGGL((k_wmrb_slice<G_, NV_, float, true>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), 0,   \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,      \
-                       (const float*)nullptr, V, (float*)nullptr, D, part)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return check_launch("tmf_wmrb_gradu_f32");
-}
 
-extern "C" int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
-                                   const float* U_old, float* U_out, int n_components, int epi, tmf_adam adam,
-                                   void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(gpos && part && U_out && n_slices > 0 && (epi == TMF_EPI_GRAD || U_old), "wmrb_finish: bad arguments");
-    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_finish: bad epilogue %d", epi);
-    const RowGeom geom = row_geom(n_components);
-#define CALL(G_, NV_)                                                                                                  \
-    {                                                                                                                  \
-        constexpr int per_block = (64 / G_) * kWaves;                                                                  \
-        hipLaunchKernelGGL((k_wmrb_finish<G_, NV_, float>), dim3((unsigned)(((int64_t)n_users + per_block - 1) / per_block)), \
-                           dim3(kThreads), 0, (hipStream_t)stream, gpos, part, (int)n_slices, (int64_t)n_users, U_old,  \
-                           (void*)U_out, epi, adam);                                                                   \
-    }
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return check_launch("tmf_wmrb_finish_f32");
-}
 
 extern "C" int tmf_wmrb_scores_hinge_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
                                          int32_t n_users, int32_t S, int32_t superbatch_users, const float* U,
@@ -677,36 +583,116 @@ extern "C" int tmf_wmrb_scores_hinge_f32(const int32_t* R_sorted, const int32_t*
     return check_launch("tmf_wmrb_scores_hinge_f32");
 }
 
-extern "C" int tmf_wmrb_gradu2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                                   int32_t n_users, int32_t S, const float* D, const float* V, float* part,
-                                   int n_components, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(R_sorted && slice_off && D && V && part && n_slices > 0 && S > 0, "wmrb_gradu2: bad arguments");
-    const RowGeom geom = row_geom(n_components);
-    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
-    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_gradu2: grid too large");
-    const size_t lds = (size_t)(64 / geom.G) * kWaves * 2 * 8 * geom.G * sizeof(int);
-#define CALL(G_, NV_)                                                                                               \
-    hipLaunchKernelGGL((k_wmrb_gradu2<G_, NV_, float>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, V, D, part)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return check_launch("tmf_wmrb_gradu2_f32");
-}
 
-extern "C" int tmf_wmrb_scores2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                                    int32_t n_users, int32_t S, const float* U, const float* V, float* sp,
-                                    int n_components, void* stream) {
+
+// ---- staged sliced pass: storage-type generic implementations + the _f32 / _bf16 entry points ----
+template <typename T>
+static int wmrb_scores2_impl(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices, int32_t n_users,
+                             int32_t S, const void* U, const void* V, float* sp, int n_components, void* stream) {
     if (n_users == 0) return TMF_OK;
     TMF_REQUIRE(R_sorted && slice_off && U && V && sp && n_slices > 0 && S > 0, "wmrb_scores2: bad arguments");
-    const RowGeom geom = row_geom(n_components);
+    const RowGeom geom = row_geom_of<T>(n_components);
     const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
     TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_scores2: grid too large");
-    const size_t lds = (size_t)(64 / geom.G) * kWaves * 2 * 8 * geom.G * sizeof(int);
-#define CALL(G_, NV_)                                                                                                \
-    hipLaunchKernelGGL((k_wmrb_scores2<G_, NV_, float>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, U, V, sp)
-    TMF_DISPATCH_GEOM(geom, CALL);
+    const size_t lds = (size_t)(64 / (geom.G ? geom.G : 1)) * kWaves * 2 * 8 * geom.G * sizeof(int);
+#define CALL(G_, NV_)                                                                                            \
+    hipLaunchKernelGGL((k_wmrb_scores2<G_, NV_, T>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,   \
+                       (const T*)U, (const T*)V, sp)
+    TMF_DISPATCH(T, geom, CALL);
 #undef CALL
-    return check_launch("tmf_wmrb_scores2_f32");
+    return check_launch("tmf_wmrb_scores2");
 }
+
+template <typename T>
+static int wmrb_hinge_impl(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp, int32_t n_users,
+                           int32_t S, float c, const void* U_old, const void* V_old, float* gpos, float* delta, float* D,
+                           float* loss_part, int n_components, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(rowptr && sp && U_old && V_old && gpos && D && n_users > 0 && S > 0, "wmrb_hinge: bad arguments");
+    const RowGeom geom = row_geom_of<T>(n_components);
+    tmf_adam none = {0.f, 0.f, 0.f, 0.f};
+#define CALL(G_, NV_)                                                                                                     \
+    return launch_wmrb_user<G_, NV_, T, true>(rowptr, col, val, nullptr, sp, nullptr, n_users, S, c, (const T*)U_old,       \
+                                              (const T*)V_old, gpos, delta, D, loss_part, nullptr, TMF_EPI_GRAD, none,     \
+                                              (hipStream_t)stream)
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return TMF_OK;
+}
+
+template <typename T>
+static int wmrb_gradu2_impl(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices, int32_t n_users,
+                            int32_t S, const float* D, const void* V, float* part, int per_slice_launches,
+                            int n_components, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(R_sorted && slice_off && D && V && part && n_slices > 0 && S > 0, "wmrb_gradu2: bad arguments");
+    const RowGeom geom = row_geom_of<T>(n_components);
+    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
+    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_gradu2: grid too large");
+    const size_t lds = (size_t)(64 / (geom.G ? geom.G : 1)) * kWaves * 2 * 8 * geom.G * sizeof(int);
+    if (per_slice_launches) {
+        for (int sl = 0; sl < n_slices; ++sl) {
+#define CALL(G_, NV_)                                                                                          \
+    hipLaunchKernelGGL((k_wmrb_gradu2<G_, NV_, T>), dim3((unsigned)groups), dim3(kThreads), lds, (hipStream_t)stream, \
+                       R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, (const T*)V, D, part, sl)
+            TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+        }
+        return check_launch("tmf_wmrb_gradu2");
+    }
+#define CALL(G_, NV_)                                                                                           \
+    hipLaunchKernelGGL((k_wmrb_gradu2<G_, NV_, T>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
+                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,  \
+                       (const T*)V, D, part, -1)
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_gradu2");
+}
+
+template <typename T>
+static int wmrb_finish_impl(const float* gpos, const float* part, int32_t n_slices, int32_t n_users, const void* U_old,
+                            void* U_out, int n_components, int epi, tmf_adam adam, void* stream) {
+    if (n_users == 0) return TMF_OK;
+    TMF_REQUIRE(gpos && part && U_out && n_slices > 0 && (epi == TMF_EPI_GRAD || U_old), "wmrb_finish: bad arguments");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_finish: bad epilogue %d", epi);
+    const RowGeom geom = row_geom_of<T>(n_components);
+#define CALL(G_, NV_)                                                                                                  \
+    {                                                                                                                  \
+        constexpr int per_block = (64 / G_) * kWaves;                                                                  \
+        hipLaunchKernelGGL((k_wmrb_finish<G_, NV_, T>), dim3((unsigned)(((int64_t)n_users + per_block - 1) / per_block)), \
+                           dim3(kThreads), 0, (hipStream_t)stream, gpos, part, (int)n_slices, (int64_t)n_users,          \
+                           (const T*)U_old, U_out, epi, adam);                                                         \
+    }
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_finish");
+}
+
+#define TMF_SLICED_ENTRY_POINTS(SFX, T_)                                                                                  \
+    extern "C" int tmf_wmrb_scores2_##SFX(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,             \
+                                          int32_t n_users, int32_t S, const void* U, const void* V, float* sp,            \
+                                          int n_components, void* stream) {                                               \
+        return wmrb_scores2_impl<T_>(R_sorted, slice_off, n_slices, n_users, S, U, V, sp, n_components, stream);           \
+    }                                                                                                                     \
+    extern "C" int tmf_wmrb_hinge_##SFX(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,     \
+                                        int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old,        \
+                                        float* gpos, float* delta, float* D, float* loss_part, int n_components,          \
+                                        void* stream) {                                                                   \
+        return wmrb_hinge_impl<T_>(rowptr, col, val, sp, n_users, S, c, U_old, V_old, gpos, delta, D, loss_part,           \
+                                   n_components, stream);                                                                 \
+    }                                                                                                                     \
+    extern "C" int tmf_wmrb_gradu2_##SFX(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,              \
+                                         int32_t n_users, int32_t S, const float* D, const void* V, float* part,          \
+                                         int per_slice_launches, int n_components, void* stream) {                        \
+        return wmrb_gradu2_impl<T_>(R_sorted, slice_off, n_slices, n_users, S, D, V, part, per_slice_launches,            \
+                                    n_components, stream);                                                                \
+    }                                                                                                                     \
+    extern "C" int tmf_wmrb_finish_##SFX(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,         \
+                                         const void* U_old, void* U_out, int n_components, int epi, tmf_adam adam,        \
+                                         void* stream) {                                                                  \
+        return wmrb_finish_impl<T_>(gpos, part, n_slices, n_users, U_old, U_out, n_components, epi, adam, stream);         \
+    }
+
+TMF_SLICED_ENTRY_POINTS(f32, float)
+TMF_SLICED_ENTRY_POINTS(bf16, __bf16)

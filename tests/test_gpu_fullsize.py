@@ -30,7 +30,7 @@ def c4():
     U0, V0 = bench.init_table(m, r, 11, dev) * 300.0, bench.init_table(n, r, 7, dev) * 100.0  # O(0.3) entries
     plan = _engine.InteractionPlan(idx, val, m, n)
     R = random_sampler_device(n, m, S, seed=100, device=dev)
-    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r)),
+    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r), n_items=n),
                              item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)))
     assert wplan.user_chunks > 1 and wplan.n_slices > 1
     Dm = None

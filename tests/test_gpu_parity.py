@@ -219,14 +219,16 @@ def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
     assert rel_err(chunked.loss_history_, base.loss_history_) < 1e-6
 
 
-@pytest.mark.parametrize('mode', ['staged', 'ticket', 'v1'])
+@pytest.mark.parametrize('mode', ['staged', 'ticket'])
 @pytest.mark.parametrize('slices', ['2', '5', '64'])
 def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, mode):
-    """TMF_ITEM_SLICES > 1: the sliced user pass instead of the fused one - scores+hinge in one launch with the
-    last-arriver hand-off (default) or the four separate kernels (TMF_SLICED_V1)."""
+    """TMF_ITEM_SLICES > 1: the sliced user pass instead of the fused one - four kernels (staged, default) or
+    scores+hinge in one launch with the last-arriver hand-off (ticket); also with per-slice gradU launches."""
     monkeypatch.setenv('TMF_ITEM_SLICES', slices)
     monkeypatch.setenv('TMF_SUPERBATCH_USERS', '256')
     monkeypatch.setenv('TMF_SLICED_MODE', mode)
+    if slices == '5':
+        monkeypatch.setattr(tm.engine, 'PART_BUDGET', 0)  # memory-light gradU: one launch per slice
     for name in ('wmrb_small', 'wmrb_mixed'):
         g = golden(name)
         model, t = check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, float(g['lr']), 'wmrb',
@@ -413,6 +415,31 @@ def test_bf16_storage_one_step(tm, r):
             lo, hi = step_bounds(W0, g, lr)
             got = got.to(torch.float32).cpu().numpy().astype(np.float64)
             assert (got >= _bf16(lo) - 1e-12).all() and (got <= _bf16(hi) + 1e-12).all(), (loss, r)
+
+
+def test_bf16_sliced_user_pass(tm, monkeypatch):
+    """bf16 tables through the staged sliced pass must give the same bits as through the fused kernel
+    (same arithmetic, different gather order is not involved: per-user sums keep their order)."""
+    monkeypatch.setenv('TMF_USER_CHUNKS', '3')
+    rng = np.random.default_rng(21)
+    m, n, r, S_ = 70, 90, 64, 31
+    A = (rng.random((m, n)) < 0.15) * rng.integers(-1, 6, (m, n))
+    idx, val = np.argwhere(A != 0), A[A != 0].astype(np.float32)
+    U0, V0 = _bf16(rng.standard_normal((m, r)) * 0.3), _bf16(rng.standard_normal((n, r)) * 0.3)
+    R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
+    out = []
+    for slices in (None, '4'):
+        if slices:
+            monkeypatch.setenv('TMF_ITEM_SLICES', slices)
+        model = tm.MF(r, loss_graph=tm.WMRB(), n_users=m, n_items=n, n_samples=S_, user_weight_graph=tm.Fixed(U0),
+                      item_weight_graph=tm.Fixed(V0))
+        model.factor_dtype, model.verbose, model.random_ind = torch.bfloat16, False, torch.as_tensor(R)
+        model.fit(3, tm.eye(m), tm.eye(n), tm.Sparse(idx, val, (m, n)), lr=0.05)
+        out.append(model)
+    assert out[1]._state.wplan.n_slices == 4
+    assert rel_err(out[1].loss_history_, out[0].loss_history_) < 1e-5
+    diff = (out[0].user_embedding.float() - out[1].user_embedding.float()).abs().max()
+    assert float(diff) <= 0.05 * 2 + 1e-6  # a step of lr either way on elements whose gradient is ~0
 
 
 def test_bf16_storage_trajectory(tm, golden):
