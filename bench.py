@@ -216,8 +216,14 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=dev)
+    dp_mode = world > 1 or os.environ.get('TMF_BENCH_FORCE_DP') == '1'  # the env knob rehearses the N>1 path on one GPU
+    if dp_mode:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29577')
+            torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        else:
+            torch.distributed.init_process_group('nccl', device_id=dev)
     _lib.get()
 
     m, n, r, S = args.users, args.items, args.r, args.samples
@@ -246,12 +252,12 @@ def main():
 
     prof = _engine.KernelTimer()
     loss_buf = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
-    if world > 1:
+    if dp_mode:
         backend = tdist.HipBackend(st, args.loss, c, adam, prof=None)
         dp = tdist.DataParallelEpoch(backend, plan.n_pos if args.loss == 'wmrb' else nnz)
 
     def step(i, p):
-        if world > 1:
+        if dp_mode:
             backend.prof = p
             loss_buf[i] = dp.step()
         else:
@@ -263,7 +269,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp_mode:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -275,7 +281,7 @@ def main():
         step(args.warmup + i, prof)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp_mode:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
@@ -350,7 +356,7 @@ def main():
         out['small_configs'] = small_configs(dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp_mode:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

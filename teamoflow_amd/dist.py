@@ -103,3 +103,65 @@ class DataParallelEpoch:
         dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
         self.b.finish()
         return self.stats[0] / self.stats[1]
+
+
+def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0, group=None):
+    """``MatrixFactorization.fit`` across the ranks of an initialised process group (one process per GPU).
+
+    Every rank passes the SAME global inputs (interactions, model.random_ind, initial weights); it keeps the
+    users of its block (``partition_users``: balanced by interactions + negatives), trains them against the
+    replicated V and exchanges the item gradient once per epoch (``DataParallelEpoch``).  On return the model
+    holds ``item_embedding`` (replicated), ``user_embedding`` = this rank's block, ``user_block`` = (begin, end);
+    ``gather_user_embedding(model)`` assembles the full table."""
+    from .mf.loss_graphs import WMRBLoss
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = interactions.device
+    wmrb = isinstance(model.loss_graph, WMRBLoss)
+    u = interactions.indices[:, 0]
+    rowptr = _engine._excl_cumsum(torch.bincount(u, minlength=n_users))
+    S = int(model.random_ind.shape[1]) if wmrb else 0
+    bounds = partition_users(rowptr, world, per_user_cost=S)
+    b, e = bounds[rank], bounds[rank + 1]
+    keep = (u >= b) & (u < e)
+    idx = interactions.indices[keep].clone()
+    idx[:, 0] -= b
+    val = interactions.values[keep]
+    n_pad = padded_rows(n_items, world)
+    plan = _engine.InteractionPlan(idx, val, e - b, n_pad)
+    ld = _lib.padded_ld(model.n_components, model.factor_dtype)
+    wplan, c = None, 0.0
+    if wmrb:
+        R = torch.as_tensor(model.random_ind)[b:e].to(device=dev, dtype=torch.int32).contiguous()
+        c = model.n_items / model.n_samples
+        wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(e - b, ld, n_items=n_pad),
+                                 item_slices=_engine.default_item_slices(n_pad, ld))
+    V0p = torch.zeros(n_pad, model.n_components, dtype=torch.float32, device=dev)
+    V0p[:n_items] = torch.as_tensor(V0).detach().to(device=dev, dtype=torch.float32)
+    st = _engine.TrainState(torch.as_tensor(U0).detach()[b:e], V0p, plan, model.n_components, wplan, dtype=model.factor_dtype)
+    adam = _engine.adam_constants(lr)
+    backend = HipBackend(st, 'wmrb' if wmrb else 'mse', c, adam)
+    dp = DataParallelEpoch(backend, plan.n_pos if wmrb else plan.nnz, group=group)
+    losses = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
+    for epoch in range(epochs):
+        losses[epoch] = dp.step()
+    torch.cuda.synchronize(dev)
+    model.loss_history_ = losses[:epochs].cpu().tolist()
+    model._state, model.user_block = st, (b, e)
+    r = model.n_components
+    model.user_embedding, model.item_embedding = st.U[:, :r], st.V[:n_items, :r]
+    model.user_trainable, model.item_trainable = [model.user_embedding], [model.item_embedding]
+
+
+def gather_user_embedding(model, n_users, group=None):
+    """Full [n_users, r] user table from the per-rank blocks (blocks are padded to the largest one)."""
+    world = dist.get_world_size(group)
+    b, e = model.user_block
+    sizes = torch.zeros(world, dtype=torch.int64, device=model.user_embedding.device)
+    sizes[dist.get_rank(group)] = e - b
+    dist.all_reduce(sizes, group=group)
+    mx = int(sizes.max())
+    mine = torch.zeros(mx, model.n_components, dtype=torch.float32, device=sizes.device)
+    mine[:e - b] = model.user_embedding.float()
+    out = torch.empty(world * mx, model.n_components, dtype=torch.float32, device=sizes.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return torch.cat([out[g * mx:g * mx + int(sizes[g])] for g in range(world)])[:n_users]

@@ -80,6 +80,7 @@ class MatrixFactorization:
         self.fit_seconds_ = 0.0   # extension: time spent in the epoch loop of the last fit
         self.verbose = True
         self.factor_dtype = torch.float32  # extension: torch.bfloat16 = bf16 factor storage, fp32 arithmetic
+        self.data_parallel = False         # extension: split the users over torch.distributed ranks (teamoflow_amd/dist.py)
 
     # ------------------------------------------------------------------------------------------
     # training
@@ -119,6 +120,13 @@ class MatrixFactorization:
         if interactions.device != dev:
             interactions = interactions.to(dev)
         wmrb = isinstance(self.loss_graph, WMRBLoss)
+        if wmrb and self.random_ind is None:
+            raise SampleTableMissing('WMRBLoss needs generate_sample=True (random_ind is None)')
+        if self.data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1 or (self.data_parallel == 'force'):
+            from .. import dist as tdist
+            tdist.fit_data_parallel(self, epochs, n_users, n_items, interactions, lr, U0, V0)
+            return
         plan = _engine.InteractionPlan(interactions.indices, interactions.values, n_users, n_items)
         wplan, c = None, 0.0
         if wmrb:

@@ -460,6 +460,38 @@ def test_bf16_storage_trajectory(tm, golden):
     assert float(model.recall_at_k(torch.tensor(g['A'])).mean()) > 0
 
 
+def test_data_parallel_fit_world_size_one_equals_single_process(tm, golden):
+    """The N>1 code path (gradient epilogue -> reduce-scatter -> Adam on the shard -> all-gather) run with a
+    1-rank RCCL group on this GPU must give the same bits as the single-process fit."""
+    import torch.distributed as dist
+    from teamoflow_amd import dist as tdist
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        for name, loss in (('wmrb_small', 'wmrb'), ('c1_mse', 'mse')):
+            g = golden(name)
+            m, n = g['A'].shape
+            args = dict(R=g.get('R'), n_items=n, n_samples=int(g['n_samples']) if loss == 'wmrb' else None)
+            base = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], (m, n), 4, float(g['lr']), loss, **args)
+            kw = dict(user_weight_graph=tm.Fixed(g['U0']), item_weight_graph=tm.Fixed(g['V0']))
+            if loss == 'wmrb':
+                kw.update(loss_graph=tm.WMRB(), n_users=m, n_items=n, n_samples=int(g['n_samples']))
+            model = tm.MF(g['U0'].shape[1], **kw)
+            model.verbose, model.data_parallel = False, 'force'
+            if loss == 'wmrb':
+                model.random_ind = torch.as_tensor(g['R'])
+            model.fit(4, tm.eye(m), tm.eye(n), tm.Sparse(g['indices'], g['values'], (m, n)), lr=float(g['lr']))
+            assert model.user_block == (0, m)
+            assert rel_err(model.loss_history_, base.loss_history_) < 1e-12
+            assert torch.equal(model.item_embedding, base.item_embedding)
+            assert torch.equal(tdist.gather_user_embedding(model, m), base.user_embedding)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_wmrb_without_sample_table_raises(tm):
     model = tm.MF(3, loss_graph=tm.WMRB(), n_users=5, n_items=6)
     with pytest.raises(AttributeError):
