@@ -226,12 +226,33 @@ __device__ __forceinline__ void add(Frag<NV>& acc, const Frag<NV>& x) {
     }
 }
 
-// Sum over the G lanes of a group (lanes [G*k, G*k+G)); every lane of the group ends with the
-// same bits (x+y == y+x), so the value can be used as a per-entry weight by all of them.
+// Sum over the G lanes of a group (lanes [G*k, G*k+G)); every lane of the group ends with the same bits
+// (x+y == y+x at every level), so the value can be used as a per-entry weight by all of them.
+// Pure VALU: DPP quad permutes (lane^1, lane^2), row_half_mirror / row_mirror (the other quad / the other
+// half-row already hold uniform sums, so a mirror is as good as an xor) and the gfx950 half-row / half-wave
+// swaps for 16 and 32 - no LDS traffic (ds_bpermute), which the gather kernels need for their staging.
+#define TMF_DPP_ADD(v, ctrl) \
+    ((v) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false)))
+
 template <int G>
 __device__ __forceinline__ float group_allsum(float v) {
+#ifdef TMF_SHUFFLE_ALLSUM
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+#endif
+    if (G >= 2) v = TMF_DPP_ADD(v, 0xB1);   // quad_perm [1,0,3,2]
+    if (G >= 4) v = TMF_DPP_ADD(v, 0x4E);   // quad_perm [2,3,0,1]
+    if (G >= 8) v = TMF_DPP_ADD(v, 0x141);  // row_half_mirror
+    if (G >= 16) v = TMF_DPP_ADD(v, 0x140); // row_mirror
+    if (G >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+        v = __int_as_float(r[0]) + __int_as_float(r[1]);
+    }
+    if (G >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+        v = __int_as_float(r[0]) + __int_as_float(r[1]);
+    }
     return v;
 }
 

@@ -46,15 +46,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
     for (int64_t k0 = beg + grp; k0 < end; k0 += (int64_t)NG * kUnroll) {
         Frag<NV> y[kUnroll];
         float a[kUnroll];
+        int j[kUnroll];
         bool ok[kUnroll];
+        // ids and values first, unconditionally (index clamped into the segment), so that the four id loads
+        // are in flight together instead of one id -> row round trip after the other
 #pragma unroll
         for (int t = 0; t < kUnroll; ++t) {
             const int64_t k = k0 + (int64_t)t * NG;
             ok[t] = k < end;
+            const int64_t kc = ok[t] ? k : end - 1;
+            j[t] = other[kc];
+            a[t] = val[kc];
+        }
+#pragma unroll
+        for (int t = 0; t < kUnroll; ++t) {
             if (ok[t]) {
-                const int j = other[k];
-                a[t] = val[k];
-                load_row<G, NV>(y[t], Y_old, j, g);
+                load_row<G, NV>(y[t], Y_old, j[t], g);
             } else {
                 a[t] = 0.f;
                 zero<NV>(y[t]);
