@@ -374,6 +374,7 @@ __device__ __forceinline__ void wmrb_slice_body(
                 ids[e] = Ru[t0 + e];
                 if (GRADU) dst[e] = D[u * (int64_t)S + t0 + e];
             }
+            float keep = 0.f;  // scores: lane g keeps the score of entry (e & (G-1)) == g until G of them are complete
             for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
                 Frag<NV> y[kUnrollW];
                 float d[kUnrollW];
@@ -391,8 +392,13 @@ __device__ __forceinline__ void wmrb_slice_body(
                     if (GRADU) {
                         axpy<NV>(acc, d[t], y[t]);
                     } else {
+                        const int e = e0 + t;
                         const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
-                        if (g == 0 && e0 + t < cnt) sp[u * (int64_t)S + t0 + e0 + t] = p;
+                        if (g == (e & (G - 1))) keep = p;
+                        // a full run of G scores (or the tail of the tile): one contiguous 4*G-byte store per group
+                        if (e < cnt && ((e & (G - 1)) == G - 1 || e == cnt - 1)) {
+                            if (g <= (e & (G - 1))) sp[u * (int64_t)S + t0 + (e & ~(G - 1)) + g] = keep;
+                        }
                     }
                 }
             }
