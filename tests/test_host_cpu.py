@@ -163,3 +163,33 @@ def test_generic_path_matches_oracle_on_cpu(golden):
     model.verbose = False
     model.fit(5, torch.eye(m), torch.eye(n), SparseInteractions(g['indices'], g['values'], (m, n)), lr=float(g['lr']))
     assert np.abs(np.array(model.loss_history_) - g['loss'][:5]).max() / g['loss'][0] < 1e-6
+
+
+def test_item_slices_and_defaults_on_cpu():
+    from teamoflow_amd import _engine
+    from teamoflow_amd._engine import InteractionPlan, WmrbPlan
+    rng = np.random.default_rng(4)
+    m, n, S, NS = 11, 50, 7, 4
+    idx = np.stack([rng.integers(0, m, 40), rng.integers(0, n, 40)], axis=1)
+    val = rng.integers(1, 4, 40).astype(np.float32)
+    plan = InteractionPlan(torch.tensor(idx), torch.tensor(val), m, n)
+    R = np.stack([rng.choice(n, S, replace=False) for _ in range(m)]).astype(np.int32)
+    w = WmrbPlan(plan, torch.tensor(R), user_chunks=2, item_slices=NS)
+    Rs = w.R.numpy()
+    assert np.array_equal(Rs, np.sort(R, axis=1))                      # negatives kept sorted by item
+    assert np.array_equal(np.take_along_axis(R, w.sample_perm.numpy(), 1), Rs)
+    width = -(-n // NS)
+    off = w.slice_off.numpy()
+    assert off.shape == (m, NS + 1) and (off[:, 0] == 0).all() and (off[:, -1] == S).all()
+    for u in range(m):
+        for sl in range(NS):
+            seg = Rs[u, off[u, sl]:off[u, sl + 1]]
+            assert ((seg >= sl * width) & (seg < (sl + 1) * width)).all()
+    # D written in sorted order maps back to the model's order
+    w.D.copy_(torch.tensor(Rs.astype(np.float32)))                      # pretend D[u, s] = item id of the sorted slot
+    assert np.array_equal(w.D_in_model_order().numpy(), R.astype(np.float32))
+    # defaults: small catalogs keep the fused pass / a single user block; C4 gets 13 slices and 123 blocks
+    assert _engine.default_item_slices(1682, 32) == 1 and _engine.default_user_chunks(943, 32, n_items=1682) == 1
+    assert _engine.default_item_slices(100_000, 128) == 13
+    assert _engine.default_user_chunks(1_000_000, 128, n_items=100_000) == 123
+    assert _engine.default_user_chunks(1_250_000, 256, n_items=1_000_000) == 8   # slab budget bounds it
