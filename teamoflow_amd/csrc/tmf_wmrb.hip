@@ -51,8 +51,8 @@ __device__ __forceinline__ void wmrb_user_body(
     int* ci = reinterpret_cast<int*>(dl + kPosChunk); // [kPosChunk] item of a positive entry, -1 otherwise
     int* Rl = ci + kPosChunk;                         // [S4] the user's negatives (fused pass only): the row gathers
                                                       //      then depend on an LDS read, not on a second global load
-    float* pm = reinterpret_cast<float*>(Rl + ((SLICED || BIG) ? 0 : S4));  // [kWaves][64] quarter partials of M_k
-    int* pc = reinterpret_cast<int*>(pm + kWaves * 64);                     // [kWaves][64] quarter partials of cnt_k
+    float* pm = reinterpret_cast<float*>(Rl + ((SLICED || BIG) ? 0 : S4));  // [2 kWaves][32] partials of M_k
+    int* pc = reinterpret_cast<int*>(pm + kWaves * 64);                     // [2 kWaves][32] partials of cnt_k
     float* red = reinterpret_cast<float*>(pc + kWaves * 64);                // [kWaves][LD] + 2*kWaves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,39 +135,58 @@ __device__ __forceinline__ void wmrb_user_body(
                 wl[kk] = 0.f;
             }
             __syncthreads();
-            // 2b: hinge sums.  Tiles of 64 interactions on the lanes; wave w sweeps sample quarter w with
-            // broadcast ds_read_b128 of sp; the four quarter partials are combined in fixed order.
+            // 2b: hinge sums.  Tiles of 32 interactions on the lanes of a half-wave; the 8 half-waves sweep one
+            // eighth of the samples each with broadcast ds_read_b128 of sp (two float4 in flight); the eight
+            // partials are combined in fixed order.
             {
-                const int nf4 = S4 / 4, per_wave = (nf4 + kWaves - 1) / kWaves;
-                const int f_beg = wave * per_wave;
-                const int f_end = (f_beg + per_wave < nf4) ? f_beg + per_wave : nf4;
+                constexpr int kSG = 2 * kWaves;  // sample groups = half-waves of the block
+                const int nf4 = S4 / 4, per_sg = (nf4 + kSG - 1) / kSG;
+                const int sg = wave * 2 + (lane >> 5), l32 = lane & 31;
+                const int f_beg = sg * per_sg;
+                const int f_end = (f_beg + per_sg < nf4) ? f_beg + per_sg : nf4;
                 const float4* sp4 = reinterpret_cast<const float4*>(sp);
-                for (int kb = 0; kb < len; kb += 64) {
-                    const int kk = kb + lane;
+                const float4 ninf4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                for (int kb = 0; kb < len; kb += 32) {
+                    const int kk = kb + l32;
                     const float c1v = (kk < len) ? c1[kk] : -INFINITY;  // -inf: every term is 0 and never counts
                     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
                     int cnt = 0;
-#pragma unroll 4
-                    for (int f = f_beg; f < f_end; ++f) {
+                    for (int f = f_beg; f < f_end; f += 2) {
                         const float4 q = sp4[f];
+                        const float4 q2 = (f + 1 < f_end) ? sp4[f + 1] : ninf4;
                         const float x0 = c1v + q.x, x1 = c1v + q.y, x2 = c1v + q.z, x3 = c1v + q.w;
+                        const float x4 = c1v + q2.x, x5 = c1v + q2.y, x6 = c1v + q2.z, x7 = c1v + q2.w;
                         m0 += fmaxf(x0, 0.f);
                         m1 += fmaxf(x1, 0.f);
                         m2 += fmaxf(x2, 0.f);
                         m3 += fmaxf(x3, 0.f);
+                        m0 += fmaxf(x4, 0.f);
+                        m1 += fmaxf(x5, 0.f);
+                        m2 += fmaxf(x6, 0.f);
+                        m3 += fmaxf(x7, 0.f);
                         count_ge0(cnt, x0);
                         count_ge0(cnt, x1);
                         count_ge0(cnt, x2);
                         count_ge0(cnt, x3);
+                        count_ge0(cnt, x4);
+                        count_ge0(cnt, x5);
+                        count_ge0(cnt, x6);
+                        count_ge0(cnt, x7);
                     }
-                    pm[wave * 64 + lane] = (m0 + m1) + (m2 + m3);
-                    pc[wave * 64 + lane] = cnt;
+                    pm[sg * 32 + l32] = (m0 + m1) + (m2 + m3);
+                    pc[sg * 32 + l32] = cnt;
                     __syncthreads();
-                    if (wave == 0 && kk < len) {
+                    if (tid < 32 && kk < len) {
                         float w = 0.f, d = 0.f;
                         if (c1v != -INFINITY) {
-                            const float M = c * ((pm[lane] + pm[64 + lane]) + (pm[128 + lane] + pm[192 + lane]));
-                            const int cn = (pc[lane] + pc[64 + lane]) + (pc[128 + lane] + pc[192 + lane]);
+                            float Ms = 0.f;
+                            int cn = 0;
+#pragma unroll
+                            for (int h = 0; h < kSG; ++h) {
+                                Ms += pm[h * 32 + tid];
+                                cn += pc[h * 32 + tid];
+                            }
+                            const float M = c * Ms;
                             lsum += logf(1.0f + M);
                             npos += 1.f;
                             w = c * __frcp_rn(1.0f + M);

@@ -492,6 +492,43 @@ def test_data_parallel_fit_world_size_one_equals_single_process(tm, golden):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_randomized_shapes_against_oracle(tm, monkeypatch, seed):
+    """Random small problems: ragged / empty rows, mixed-sign values, every path selector (fused or sliced
+    user pass, user-blocked item lists, fp32 or bf16-free) - one step each against the fp64 closed form."""
+    rng = np.random.default_rng(1000 + seed)
+    m, n = int(rng.integers(1, 60)), int(rng.integers(2, 80))
+    r = int(rng.choice([1, 2, 5, 8, 17, 32, 48, 64, 96, 128, 160, 257]))
+    S_ = int(rng.integers(1, n + 1))
+    density = float(rng.choice([0.0, 0.02, 0.1, 0.5]))
+    A = (rng.random((m, n)) < density) * rng.integers(-2, 6, (m, n))
+    if seed % 4 == 1:
+        A[rng.integers(0, m)] = rng.integers(1, 6, n)      # one user interacted with everything
+    idx, val = np.argwhere(A != 0), A[A != 0].astype(np.float32)
+    if seed % 3 == 0 and len(val):                          # shuffle: the engine must not rely on row-major order
+        p = rng.permutation(len(val))
+        idx, val = idx[p], val[p]
+    U0 = (rng.standard_normal((m, r)) * 0.4).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.4).astype(np.float32)
+    R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
+    lr = float(rng.choice([1e-3, 1e-2, 0.1]))
+    if seed % 2:
+        monkeypatch.setenv('TMF_ITEM_SLICES', str(int(rng.integers(2, 9))))
+    if seed % 3 == 2:
+        monkeypatch.setenv('TMF_USER_CHUNKS', str(int(rng.integers(2, 6))))
+    if len(val):
+        check_one_step(tm, U0, V0, idx, val, (m, n), lr)
+    if (val > 0).any():
+        model, t = check_one_step(tm, U0, V0, idx, val, (m, n), lr, 'wmrb', R, n, S_)
+        assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
+        top = model.retrieve_user_recs(k=min(5, n))
+        from oracle import sparse_ref as S
+        sc = (model.user_embedding.float() @ model.item_embedding.float().T).cpu().numpy()
+        pred = tm.ops.predict_gemm(model.user_embedding, model.item_embedding).cpu().numpy()
+        assert np.array_equal(top, S.topk_stable(pred, min(5, n)))
+        assert rel_err(pred, sc) < 1e-5
+
+
 def test_wmrb_without_sample_table_raises(tm):
     model = tm.MF(3, loss_graph=tm.WMRB(), n_users=5, n_items=6)
     with pytest.raises(AttributeError):
