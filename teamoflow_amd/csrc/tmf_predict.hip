@@ -399,25 +399,26 @@ __global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict
             }
         }
     };
-    auto merge = [&]() {  // thread t < FBM merges row t's pending candidates
-        if (tid < FBM) {
-            const int c = cnt[tid] < FCAP ? cnt[tid] : FCAP;
+    auto merge_wave = [&]() {  // lanes 0..31 of a wave merge the pending candidates of the wave's own rows
+        if (h == 0) {
+            const int row = 32 * wave + l31;
+            const int c = cnt[row] < FCAP ? cnt[row] : FCAP;
             for (int p = 0; p < c; ++p) {
-                const float v = pend_v[p * FBM + tid];
-                const int ix = pend_i[p * FBM + tid];
+                const float v = pend_v[p * FBM + row];
+                const int ix = pend_i[p * FBM + row];
                 int j = k - 1;
-                if (before(v, ix, list_v[j * FBM + tid], list_i[j * FBM + tid])) {
-                    while (j > 0 && before(v, ix, list_v[(j - 1) * FBM + tid], list_i[(j - 1) * FBM + tid])) {
-                        list_v[j * FBM + tid] = list_v[(j - 1) * FBM + tid];
-                        list_i[j * FBM + tid] = list_i[(j - 1) * FBM + tid];
+                if (before(v, ix, list_v[j * FBM + row], list_i[j * FBM + row])) {
+                    while (j > 0 && before(v, ix, list_v[(j - 1) * FBM + row], list_i[(j - 1) * FBM + row])) {
+                        list_v[j * FBM + row] = list_v[(j - 1) * FBM + row];
+                        list_i[j * FBM + row] = list_i[(j - 1) * FBM + row];
                         --j;
                     }
-                    list_v[j * FBM + tid] = v;
-                    list_i[j * FBM + tid] = ix;
+                    list_v[j * FBM + row] = v;
+                    list_i[j * FBM + row] = ix;
                 }
             }
-            cnt[tid] = 0;
-            if (row0 + tid < m) tau[tid] = list_v[(k - 1) * FBM + tid];
+            cnt[row] = 0;
+            if (row0 + row < m) tau[row] = list_v[(k - 1) * FBM + row];
         }
     };
 
@@ -442,27 +443,23 @@ __global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict
             s_write((int)((g + 2) % 3));
             __syncthreads();
         }
+        // top-k update: the 32 rows of a wave are touched by that wave only (pending lists, thresholds, sorted
+        // lists), so this part needs no workgroup barrier - LDS operations of one wave complete in order.
         const int64_t col0 = tile * FBN;
         offer(col0, -1);
-        __syncthreads();
-        if (tid < FBM && cnt[tid] > FCAP) ovf[0] = 1;
-        __syncthreads();
-        if (ovf[0]) {  // block-uniform: re-offer the tile in 8 groups of 16 columns
-            __syncthreads();
-            if (tid < FBM) cnt[tid] = 0;
-            if (tid == 0) ovf[0] = 0;
-            __syncthreads();
+        const int my_row = 32 * wave + l31;
+        const bool over = __any((h == 0) && cnt[my_row] > FCAP);  // wave-uniform
+        if (over) {  // re-offer the tile in 8 groups of 16 columns
+            if (h == 0) cnt[my_row] = 0;
             for (int grp = 0; grp < FBN / 16; ++grp) {
                 offer(col0, grp);
-                __syncthreads();
-                merge();
-                __syncthreads();
+                merge_wave();
             }
         } else {
-            merge();
-            __syncthreads();
+            merge_wave();
         }
     }
+    __syncthreads();
     if (tid < FBM && row0 + tid < m) {
         for (int j = 0; j < k; ++j) {
             out_idx[(row0 + tid) * k + j] = list_i[j * FBM + tid];

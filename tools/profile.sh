@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence for `python bench.py --no-extras` on the GPU box:
 #   kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc passes (never combined with
-#   other trace domains).  Usage on the box:  bash tools_profile.sh <tag>   -> gpurun_out/prof_<tag>/
+#   other trace domains).  Usage on the box:  bash tools/profile.sh <tag>   -> gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-run}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,4 +12,4 @@ cd /tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-extras > $OUT/bench_trace.json 2> $OUT/trace.err
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_fetch.err
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_write.err
-python3 $R/tools_profile_summary.py $OUT $TAG
+python3 $R/tools/profile_summary.py $OUT $TAG

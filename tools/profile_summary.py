@@ -8,7 +8,7 @@ import os
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-root = os.path.dirname(os.path.abspath(__file__))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(src, 'summary')
 os.makedirs(dst, exist_ok=True)
 rows = list(csv.DictReader(open(glob.glob(src + '/trace/*/*_kernel_stats.csv')[0])))
