@@ -337,8 +337,6 @@ def main():
             out['cpu_baseline'] = cpu_baseline_wmrb(idx, val, R, U0, V0[:n], n, S, args.lr)
         # predict rows/s: stable top-10 over the full catalog, fused GEMM + top-k (no [m, n] matrix)
         Ue, Ve = st.U[:, :r], st.V[:n, :r]
-        if args.dtype == 'bf16':
-            Ue, Ve = Ue[:262144].float(), Ve.float()
         rows = min(m, 262144)
         _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True)
         torch.cuda.synchronize()
@@ -348,8 +346,9 @@ def main():
         dt = time.perf_counter() - t1
         out['predict_rows_per_sec'] = rows / dt
         out['predict_tflops'] = 2.0 * rows * n * r / dt / 1e12
-        out['predict_note'] = (f'stable top-10 of U.V^T over all {n} items for {rows} users, fused fp32-MFMA GEMM + top-k '
-                               f'(tmf_predict_topk_f32); fp32 MFMA peak 157.3 TF')
+        out['predict_note'] = (f'stable top-10 of U.V^T over all {n} items for {rows} users, fused MFMA GEMM + top-k '
+                               + ('(tmf_predict_topk_bf16: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)' if args.dtype == 'bf16'
+                                  else '(tmf_predict_topk_f32: exact-fp32 MFMA, peak 157.3 TF)'))
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want), case='C1 golden fixture')
     if rank == 0 and world == 1 and args.small_configs:

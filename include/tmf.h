@@ -218,6 +218,12 @@ int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, int64_t n, i
                          int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
                          void* stream);
 
+/* The same for bf16-stored tables (A [m, lda], B [n, ldb] bf16, ld %% 8 == 0) on the bf16 MFMA: products of
+ * bf16 values are exact and accumulate in fp32 ("bf16 factors / fp32 accum").  k <= 32, r <= 256. */
+int tmf_predict_topk_bf16(const void* A, const void* B, int64_t m, int64_t n, int r, int64_t lda,
+                          int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

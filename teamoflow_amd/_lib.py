@@ -69,6 +69,7 @@ _BASE_SIGNATURES = {
     'tmf_predict_gemm_f32': (_I, [_P, _P, _P, _L, _L, _I, _L, _L, _L, _P]),
     'tmf_topk_stable_f32': (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
     'tmf_predict_topk_f32': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P]),
+    'tmf_predict_topk_bf16': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P]),
 }
 
 SIGNATURES.update(_BASE_SIGNATURES)

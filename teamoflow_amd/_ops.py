@@ -42,13 +42,46 @@ def predict_gemm(user_embedding, item_embedding, out=None):
     return out
 
 
-FUSED_MAX_K, FUSED_MAX_R = 32, 128
+FUSED_MAX_K, FUSED_MAX_R, FUSED_MAX_R_BF16 = 32, 128, 256
+
+
+def _bf16_operand(t):
+    """[rows, r] bf16 tensor -> (tensor, rows, r, ld) with 16-byte aligned rows (ld % 8 == 0)."""
+    t = t.detach()
+    rows, r = t.shape
+    ok = t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.stride(0) >= r and t.data_ptr() % 16 == 0
+    if not ok:
+        ld = (r + 7) // 8 * 8
+        p = torch.zeros(rows, ld, dtype=torch.bfloat16, device=t.device)
+        p[:, :r] = t
+        t = p[:, :r]
+    return t, rows, r, t.stride(0)
+
+
+def fused_topk_supported(user_embedding, item_embedding, k):
+    bf16 = user_embedding.dtype == torch.bfloat16 and item_embedding.dtype == torch.bfloat16
+    return k <= FUSED_MAX_K and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
 
 
 def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False):
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
-    Only for k <= 32 and width <= 128; see topk_stable(predict_gemm(...)) for the general case."""
+    fp32 tables: exact-fp32 MFMA, k <= 32, width <= 128.  bf16 tables (both operands): bf16 MFMA with fp32
+    accumulation, width <= 256.  See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
+    if torch.is_tensor(user_embedding) and torch.is_tensor(item_embedding) and \
+            user_embedding.dtype == torch.bfloat16 and item_embedding.dtype == torch.bfloat16:
+        A, m, r, lda = _bf16_operand(_cuda(user_embedding))
+        B, n, rb, ldb = _bf16_operand(_cuda(item_embedding))
+        if r != rb:
+            raise ValueError(f'embedding widths differ: {r} vs {rb}')
+        k = int(k)
+        if not 1 <= k <= n:
+            raise ValueError(f'k={k} must be in [1, {n}]')
+        idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
+        vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
+        _lib.check(lib.tmf_predict_topk_bf16(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
+                                             _lib.ptr(idx), _lib.ptr(vals), _lib.stream_ptr()), lib)
+        return (vals, idx) if return_values else idx
     A, m, r, lda = _gemm_operand(user_embedding)
     B, n, rb, ldb = _gemm_operand(item_embedding)
     if r != rb:

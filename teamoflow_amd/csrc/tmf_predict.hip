@@ -506,3 +506,218 @@ extern "C" int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, i
     if (r <= 64) return tmf::launch_predict_topk<2>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
     return tmf::launch_predict_topk<4>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
 }
+
+// =============================================================================================
+// Fused top-k for bf16-stored factors (BASELINE config 5): the same structure as k_predict_topk on the bf16
+// MFMA (v_mfma_f32_32x32x16_bf16: exact bf16 products, fp32 accumulation - i.e. "bf16 factors / fp32 accum").
+// 512 threads = 8 waves own 256 users (32 per wave, rows in registers as A fragments: 8 bf16 per lane and
+// k-step); item tiles of 128 stream through a 3-slot LDS ring in k-chunks of 64 (128-byte rows padded to 144
+// bytes: 16 consecutive rows then hit 16 different 16-byte bank slots, so the ds_read_b128 operand reads are
+// conflict-free).  256 users per workgroup halve the V bytes streamed per flop, which is what bounds this kernel.
+// =============================================================================================
+namespace tmf {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int HBM_ = 256, HBN = 128, HBK = 64, HROW = 144 /* bytes */, HCAP = 8, HMAXK = 32;
+
+template <int NCH>  // K_PAD = 64 * NCH
+__global__ __launch_bounds__(512, 2) void k_predict_topk_bf16(const __bf16* __restrict__ A, const __bf16* __restrict__ B,
+                                                              int64_t m, int64_t n, int K, int64_t lda, int64_t ldb, int k,
+                                                              int clamp, int32_t* __restrict__ out_idx,
+                                                              float* __restrict__ out_val) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* Bs = smem_raw;                                               // [3][HBN][HROW] bytes
+    float* tau = reinterpret_cast<float*>(Bs + 3 * HBN * HROW);        // [HBM_]
+    int* cnt = reinterpret_cast<int*>(tau + HBM_);                     // [HBM_]
+    float* pend_v = reinterpret_cast<float*>(cnt + HBM_);              // [HCAP][HBM_]
+    int* pend_i = reinterpret_cast<int*>(pend_v + HCAP * HBM_);
+    float* list_v = reinterpret_cast<float*>(pend_i + HCAP * HBM_);    // [k][HBM_]
+    int* list_i = reinterpret_cast<int*>(list_v + (size_t)k * HBM_);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * HBM_;
+
+    // A fragments: a[kk] = U[row0 + 32 wave + l31][16 kk + 8 h .. + 8)
+    bf16x8_t a[4 * NCH];
+    {
+        const int64_t r = row0 + 32 * wave + l31;
+        const __bf16* p = A + (r < m ? r : 0) * lda;
+#pragma unroll
+        for (int kk = 0; kk < 4 * NCH; ++kk) {
+            bf16x8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+            const int k0 = 16 * kk + 8 * h;
+            if (r < m && k0 < K) {
+                if (k0 + 7 < K) v = *reinterpret_cast<const bf16x8_t*>(p + k0);
+                else
+                    for (int e = 0; e < 8; ++e) if (k0 + e < K) v[e] = p[k0 + e];
+            }
+            a[kk] = v;
+        }
+    }
+    for (int t = tid; t < HBM_; t += 512) {
+        tau[t] = (row0 + t < m) ? -INFINITY : INFINITY;
+        cnt[t] = 0;
+        for (int j = 0; j < k; ++j) { list_v[j * HBM_ + t] = -INFINITY; list_i[j * HBM_ + t] = 0x7fffffff; }
+    }
+
+    // staging: thread -> (item = tid/8 + 64 q, 16-byte slot tid%8 of the 128-byte k-chunk), q = 0, 1
+    const int s_item = tid >> 3, s_slot = tid & 7;
+    const int64_t ntiles = (n + HBN - 1) / HBN;
+    const int64_t nchunks = ntiles * NCH;
+    bf16x8_t stage[2];
+    auto g_load = [&](int64_t g) {
+        const int64_t tile = g / NCH;
+        const int c = (int)(g % NCH);
+        const int kk = 64 * c + 8 * s_slot;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t item = tile * HBN + s_item + 64 * q;
+            bf16x8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+            if (g < nchunks && item < n && kk < K) {
+                const __bf16* p = B + item * ldb + kk;
+                if (kk + 7 < K) v = *reinterpret_cast<const bf16x8_t*>(p);
+                else
+                    for (int e = 0; e < 8; ++e) if (kk + e < K) v[e] = p[e];
+            }
+            stage[q] = v;
+        }
+    };
+    auto s_write = [&](int slot) {
+        char* dst = Bs + slot * HBN * HROW;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<bf16x8_t*>(dst + (s_item + 64 * q) * HROW + s_slot * 16) = stage[q];
+    };
+    g_load(0); s_write(0);
+    g_load(1); s_write(1);
+    __syncthreads();
+
+    f32x16 acc[4];
+    auto offer = [&](int64_t col0, int group) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float t = tau[row];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lc = 32 * j + l31;
+                float v = acc[j][q];
+                if (clamp) v = (v > 0.f) ? v : 0.f;
+                const bool in_group = (group < 0) || ((lc >> 3) == group);
+                if (in_group && (col0 + lc < n) && v > t) {
+                    const int pos = atomicAdd(&cnt[row], 1);
+                    if (pos < HCAP) { pend_v[pos * HBM_ + row] = v; pend_i[pos * HBM_ + row] = (int)(col0 + lc); }
+                }
+            }
+        }
+    };
+    auto merge_wave = [&]() {
+        if (h == 0) {
+            const int row = 32 * wave + l31;
+            const int c = cnt[row] < HCAP ? cnt[row] : HCAP;
+            for (int p = 0; p < c; ++p) {
+                const float v = pend_v[p * HBM_ + row];
+                const int ix = pend_i[p * HBM_ + row];
+                int j = k - 1;
+                if (before(v, ix, list_v[j * HBM_ + row], list_i[j * HBM_ + row])) {
+                    while (j > 0 && before(v, ix, list_v[(j - 1) * HBM_ + row], list_i[(j - 1) * HBM_ + row])) {
+                        list_v[j * HBM_ + row] = list_v[(j - 1) * HBM_ + row];
+                        list_i[j * HBM_ + row] = list_i[(j - 1) * HBM_ + row];
+                        --j;
+                    }
+                    list_v[j * HBM_ + row] = v;
+                    list_i[j * HBM_ + row] = ix;
+                }
+            }
+            cnt[row] = 0;
+            if (row0 + row < m) tau[row] = list_v[(k - 1) * HBM_ + row];
+        }
+    };
+
+    int64_t g = 0;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c, ++g) {
+            g_load(g + 2);
+            const char* bs = Bs + (int)(g % 3) * HBN * HROW;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(bs + (32 * j + l31) * HROW + ks * 32 + h * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 * c + ks], b, acc[j], 0, 0, 0);
+                }
+            }
+            s_write((int)((g + 2) % 3));
+            __syncthreads();
+        }
+        const int64_t col0 = tile * HBN;
+        offer(col0, -1);
+        const int my_row = 32 * wave + l31;
+        const bool over = __any((h == 0) && cnt[my_row] > HCAP);
+        if (over) {  // re-offer the tile in 16 groups of 8 columns
+            if (h == 0) cnt[my_row] = 0;
+            for (int grp = 0; grp < HBN / 8; ++grp) {
+                offer(col0, grp);
+                merge_wave();
+            }
+        } else {
+            merge_wave();
+        }
+    }
+    __syncthreads();
+    if (tid < HBM_ && row0 + tid < m) {
+        for (int j = 0; j < k; ++j) {
+            out_idx[(row0 + tid) * k + j] = list_i[j * HBM_ + tid];
+            if (out_val) out_val[(row0 + tid) * k + j] = list_v[j * HBM_ + tid];
+        }
+    }
+}
+
+template <int NCH>
+static int launch_predict_topk_bf16(const void* A, const void* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
+                                    int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
+    const size_t lds = (size_t)3 * HBN * HROW + sizeof(float) * HBM_ + sizeof(int) * HBM_ + 8 * (size_t)HCAP * HBM_ +
+                       8 * (size_t)k * HBM_;
+    static size_t allowed = 64 * 1024;
+    if (lds > allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk_bf16<NCH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return TMF_E_LAUNCH; }
+        allowed = lds;
+    }
+    const int64_t blocks = (m + HBM_ - 1) / HBM_;
+    hipLaunchKernelGGL((k_predict_topk_bf16<NCH>), dim3((unsigned)blocks), dim3(512), lds, stream, (const __bf16*)A,
+                       (const __bf16*)B, m, n, K, lda, ldb, k, clamp, out_idx, out_val);
+    return check_launch("tmf_predict_topk_bf16");
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_predict_topk_bf16(const void* A, const void* B, int64_t m, int64_t n, int r, int64_t lda,
+                                     int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
+                                     void* stream) {
+    if (m == 0) return TMF_OK;
+    TMF_REQUIRE(A && B && out_idx && m > 0 && n > 0 && r > 0, "predict_topk_bf16: bad arguments");
+    TMF_REQUIRE(lda >= r && ldb >= r && (lda % 8 == 0) && (ldb % 8 == 0) && ((uintptr_t)A % 16 == 0) &&
+                    ((uintptr_t)B % 16 == 0), "predict_topk_bf16: operands must be 16-byte aligned with ld %% 8 == 0");
+    TMF_REQUIRE(k >= 1 && k <= n, "predict_topk_bf16: k=%d must be in [1, n=%lld]", k, (long long)n);
+    TMF_REQUIRE(n < ((int64_t)1 << 31), "predict_topk_bf16: too many items");
+    if (k > tmf::HMAXK || r > 256) {
+        tmf::set_error("predict_topk_bf16: supports k <= %d and n_components <= 256 (got k=%d, r=%d)", tmf::HMAXK, k, r);
+        return TMF_E_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (r <= 64) return tmf::launch_predict_topk_bf16<1>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+    if (r <= 128) return tmf::launch_predict_topk_bf16<2>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+    return tmf::launch_predict_topk_bf16<4>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+}

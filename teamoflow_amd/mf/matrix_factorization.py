@@ -280,7 +280,7 @@ class MatrixFactorization:
         if users is not None:
             scores = _ops.predict_gemm(self.user_embedding[users:users + 1], self.item_embedding)
             return _ops.topk_stable(scores, k, clamp_negatives=clamp)[0]
-        if k <= _ops.FUSED_MAX_K and self.user_embedding.shape[1] <= _ops.FUSED_MAX_R:
+        if _ops.fused_topk_supported(self.user_embedding, self.item_embedding, k):
             return _ops.predict_topk(self.user_embedding, self.item_embedding, k, clamp_negatives=clamp)
         out = []
         for b, e in self._user_blocks():

@@ -352,6 +352,35 @@ def test_fused_predict_topk_matches_materialised_and_oracle(tm):
         tm.ops.predict_topk(torch.ones(3, 4), torch.ones(10, 4), 33 if False else 11)
 
 
+def test_fused_predict_topk_bf16(tm):
+    """bf16 tables on the bf16 MFMA: with small-integer factors every product and partial sum is exact, so the
+    ranking must equal the fp32 path bit for bit (ties included); random factors are compared by value."""
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(17)
+    for m, n, r in [(1, 9, 3), (300, 515, 40), (257, 1000, 64), (513, 2051, 128), (100, 700, 256), (64, 300, 200)]:
+        U = rng.integers(-2, 3, (m, r)).astype(np.float32)
+        V = rng.integers(-2, 3, (n, r)).astype(np.float32)
+        Ub, Vb = torch.tensor(U).to(torch.bfloat16).cuda(), torch.tensor(V).to(torch.bfloat16).cuda()
+        sc = U @ V.T
+        for k in sorted({1, min(10, n), min(32, n)}):
+            for clamp in (False, True):
+                vals, got = tm.ops.predict_topk(Ub, Vb, k, clamp_negatives=clamp, return_values=True)
+                ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
+                assert np.array_equal(got.cpu().numpy(), ref), (m, n, r, k, clamp)
+                want = np.take_along_axis(np.where(sc > 0, sc, 0) if clamp else sc, ref, 1)
+                assert np.array_equal(vals.cpu().numpy(), want)
+    U = torch.tensor(rng.standard_normal((700, 256)).astype(np.float32)).to(torch.bfloat16).cuda()
+    V = torch.tensor(rng.standard_normal((5000, 256)).astype(np.float32)).to(torch.bfloat16).cuda()
+    vals, idx = tm.ops.predict_topk(U, V, 10, return_values=True)
+    sc = U.float() @ V.float().T
+    want = torch.sort(sc, dim=1, descending=True)[0][:, :10]
+    assert rel_err(vals.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    assert rel_err(torch.gather(sc, 1, idx.to(torch.int64)).cpu().numpy(), vals.cpu().numpy()) < 1e-5
+    model = tm.MF(256)
+    model.user_embedding, model.item_embedding = U, V
+    assert np.array_equal(model.retrieve_user_recs(k=10), idx.cpu().numpy())
+
+
 def test_predict_gemm_shapes(tm):
     rng = np.random.default_rng(3)
     for m, n, r in [(1, 1, 1), (100, 50, 5), (129, 257, 32), (300, 1000, 128), (64, 64, 7)]:
