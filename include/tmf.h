@@ -72,6 +72,8 @@ typedef struct tmf_segments {
     const int32_t* seg_slab;  /* [nseg] */
     int64_t nseg;
     int32_t chunk;
+    int32_t row_mod; /* 0, or n_rows when the lists are split by blocks of the OTHER side: list row =
+                        block * n_rows + table row (every segment then owns a slab slot) */
 } tmf_segments;
 
 /* K1+K2 / K3: one side of an MSE epoch (loss_graphs.py:47-52 forward; tape.gradient

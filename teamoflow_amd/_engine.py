@@ -31,7 +31,7 @@ class SegmentTable:
     slab slot, slots are numbered table-row-major, and all ``n_out`` table rows are finished by
     tmf_combine_rows."""
 
-    def __init__(self, rowptr, chunk=DEFAULT_CHUNK, out_row=None, n_out=None):
+    def __init__(self, rowptr, chunk=DEFAULT_CHUNK, out_row=None, n_out=None, row_mod=0):
         dev = rowptr.device
         rows = rowptr.numel() - 1
         lens = rowptr[1:] - rowptr[:-1]
@@ -56,7 +56,7 @@ class SegmentTable:
             long_rows = torch.arange(n_out, device=dev)
             self.n_slab = nseg
             self.long_slab_beg = _excl_cumsum(torch.bincount(seg_out, minlength=n_out))
-        self.rows, self.chunk, self.nseg = rows, int(chunk), nseg
+        self.rows, self.chunk, self.nseg, self.row_mod = rows, int(chunk), nseg, int(row_mod)
         self.rowptr = rowptr.contiguous()
         self.seg_row = seg_row.to(torch.int32)
         self.seg_chunk = seg_chunk.to(torch.int32)
@@ -68,14 +68,14 @@ class SegmentTable:
     def cstruct(self):
         if self._c is None:
             self._c = _lib.Segments(self.rowptr.data_ptr(), self.seg_row.data_ptr(), self.seg_chunk.data_ptr(),
-                                    self.seg_slab.data_ptr(), self.nseg, self.chunk)
+                                    self.seg_slab.data_ptr(), self.nseg, self.chunk, self.row_mod)
         return ctypes.byref(self._c)
 
 
 class InteractionPlan:
     """CSR-by-user and CSC-by-item views of the interactions (values duplicated in both orders)."""
 
-    def __init__(self, indices, values, n_users, n_items, chunk=DEFAULT_CHUNK):
+    def __init__(self, indices, values, n_users, n_items, chunk=DEFAULT_CHUNK, user_chunks=1):
         dev = indices.device
         u = indices[:, 0].contiguous()
         j = indices[:, 1].contiguous()
@@ -90,13 +90,26 @@ class InteractionPlan:
         self.rowptr_u = _excl_cumsum(torch.bincount(u, minlength=n_users))
         self.col_u = j.to(torch.int32)
         self.val_u = values.contiguous()
-        perm_c = torch.sort(j, stable=True)[1]
-        self.rowptr_i = _excl_cumsum(torch.bincount(j, minlength=n_items))
+        # CSC by item; with user_chunks = C > 1 by (user block, item), blocks outermost, so that the U rows the
+        # item pass gathers at any time come from one cache-sized block of users (same idea as WmrbPlan)
+        C = max(1, int(user_chunks))
+        self.user_chunks = C
+        if C > 1:
+            upc = -(-n_users // C)
+            key = (u // upc) * n_items + j
+        else:
+            key = j
+        perm_c = torch.sort(key, stable=True)[1]
+        self.rowptr_i = _excl_cumsum(torch.bincount(key, minlength=C * n_items))
         self.row_i = u[perm_c].to(torch.int32)
         self.val_i = values[perm_c].contiguous()
         self.csc_to_csr = perm_c
         self.seg_u = SegmentTable(self.rowptr_u, chunk)
-        self.seg_i = SegmentTable(self.rowptr_i, chunk)
+        if C > 1:
+            out_row = torch.arange(C * n_items, device=dev) % n_items
+            self.seg_i = SegmentTable(self.rowptr_i, chunk, out_row=out_row, n_out=n_items, row_mod=n_items)
+        else:
+            self.seg_i = SegmentTable(self.rowptr_i, chunk)
         self.n_pos = int((values > 0).sum())
         self.user_ids = u  # int64, CSR order (kept for the WMRB entry lists)
 
@@ -116,6 +129,14 @@ def default_user_chunks(n_users, ld, target_bytes=4 << 20, n_items=None):
     if n_items:  # every (block, item) list owns at least one fp32 partial row: keep that slab within budget
         c = min(c, max(1, SLAB_BUDGET // (n_items * ld * 4)))
     return int(min(max(c, 1), 256)) if c > 1 else 1
+
+
+def mse_user_chunks():
+    """User blocks for the MSE item pass (CSC by (user block, item)).  Off by default: MSE lists are short (81M
+    entries over 100K items at C4 against 1.1e9 for WMRB), so splitting them buys nothing - item pass 5.73 ms with
+    1 block, 5.49 with 32, 8.57 with 123.  TMF_USER_CHUNKS forces a value (tests)."""
+    env = os.environ.get('TMF_USER_CHUNKS')
+    return max(1, int(env)) if env else 1
 
 
 def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20):

@@ -31,7 +31,8 @@ class Adam(ctypes.Structure):
 
 class Segments(ctypes.Structure):
     _fields_ = [('rowptr', ctypes.c_void_p), ('seg_row', ctypes.c_void_p), ('seg_chunk', ctypes.c_void_p),
-                ('seg_slab', ctypes.c_void_p), ('nseg', ctypes.c_int64), ('chunk', ctypes.c_int32)]
+                ('seg_slab', ctypes.c_void_p), ('nseg', ctypes.c_int64), ('chunk', ctypes.c_int32),
+                ('row_mod', ctypes.c_int32)]
 
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float

@@ -16,6 +16,7 @@ struct SegView {
     const int32_t* seg_slab;
     int64_t nseg;
     int32_t chunk;
+    int32_t row_mod;  // > 0: list rows are (block * row_mod + table row); 0: list row == table row
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -33,8 +34,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
     const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (seg >= sv.nseg) return;
     const int g = lane & (G - 1), grp = lane / G;
-    const int row = sv.seg_row[seg];
-    const int64_t rbeg = sv.rowptr[row], rend = sv.rowptr[row + 1];
+    const int lrow = sv.seg_row[seg];
+    const int row = sv.row_mod > 0 ? lrow % sv.row_mod : lrow;  // table row this list belongs to
+    const int64_t rbeg = sv.rowptr[lrow], rend = sv.rowptr[lrow + 1];
     const int64_t beg = rbeg + (int64_t)sv.seg_chunk[seg] * sv.chunk;
     const int64_t end = (beg + sv.chunk < rend) ? beg + sv.chunk : rend;
 
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_sum_f32(const float* __restrict__ x, i
 }
 
 static inline SegView view(const tmf_segments* s) {
-    return SegView{s->rowptr, s->seg_row, s->seg_chunk, s->seg_slab, s->nseg, s->chunk};
+    return SegView{s->rowptr, s->seg_row, s->seg_chunk, s->seg_slab, s->nseg, s->chunk, s->row_mod};
 }
 
 static int check_segments(const tmf_segments* s) {

@@ -127,7 +127,9 @@ class MatrixFactorization:
             from .. import dist as tdist
             tdist.fit_data_parallel(self, epochs, n_users, n_items, interactions, lr, U0, V0)
             return
-        plan = _engine.InteractionPlan(interactions.indices, interactions.values, n_users, n_items)
+        ld = _lib.padded_ld(self.n_components, self.factor_dtype)
+        plan = _engine.InteractionPlan(interactions.indices, interactions.values, n_users, n_items,
+                                       user_chunks=_engine.mse_user_chunks())
         wplan, c = None, 0.0
         if wmrb:
             if self.random_ind is None:

@@ -264,6 +264,18 @@ def test_wmrb_n_samples_beyond_lds_uses_global_workspace(tm):
     assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
 
 
+def test_mse_user_blocked_item_pass(tm, golden, monkeypatch):
+    """TMF_USER_CHUNKS > 1 with MSE: the item pass walks (user block, item) lists; every segment through slab + combine."""
+    monkeypatch.setenv('TMF_USER_CHUNKS', '4')
+    for name in ('c1_mse', 'wmrb_mixed'):
+        g = golden(name)
+        model, _ = check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, float(g['lr']))
+        assert model._state.plan.user_chunks == 4 and model._state.plan.seg_i.row_mod == g['A'].shape[1]
+    g = golden('c1_mse')
+    blocked = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 25, float(g['lr']))
+    assert rel_err(blocked.loss_history_, g['loss'][:25]) < 1e-5
+
+
 def test_heavy_rows_are_segmented_and_combined(tm):
     """Rows longer than the segment length go through the slab + combine path."""
     rng = np.random.default_rng(7)

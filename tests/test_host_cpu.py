@@ -68,6 +68,18 @@ def test_segment_table_and_plans_against_numpy():
     assert np.array_equal(plan.rowptr_u.numpy(), np.concatenate([[0], np.cumsum(np.bincount(u, minlength=m))]))
     oc = np.argsort(j, kind='stable')
     assert np.array_equal(plan.row_i.numpy(), u[oc]) and np.array_equal(plan.val_i.numpy(), v[oc])
+    # user-blocked CSC (MSE item pass): list row = block * n + item, same multiset of entries per item
+    pb = InteractionPlan(torch.tensor(idx), torch.tensor(val), m, n, chunk=chunk, user_chunks=3)
+    upc = -(-m // 3)
+    rpb = pb.rowptr_i.numpy()
+    assert len(rpb) == 3 * n + 1 and pb.seg_i.row_mod == n and (pb.seg_i.seg_slab.numpy() >= 0).all()
+    for item in range(n):
+        got = []
+        for blk in range(3):
+            rows = pb.row_i.numpy()[rpb[blk * n + item]:rpb[blk * n + item + 1]]
+            assert ((rows // upc) == blk).all()
+            got += list(rows)
+        assert sorted(got) == sorted(u[j == item])
     # segments: every entry covered exactly once, slab slots consecutive per long row
     seg = plan.seg_u
     covered = np.zeros(len(v), int)
