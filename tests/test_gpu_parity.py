@@ -570,6 +570,36 @@ def test_randomized_shapes_against_oracle(tm, monkeypatch, seed):
         assert rel_err(pred, sc) < 1e-5
 
 
+def test_c_abi_error_codes_and_messages(tm):
+    """Bad arguments come back as negative codes with a message, never as a launch on bad pointers."""
+    import ctypes
+    lib = tm.lib.get()
+    adam = lib.tmf_adam_fresh(0.01)
+    s = tm.lib.stream_ptr()
+    x = torch.zeros(8, 8, device='cuda')
+    out = torch.zeros(8, 8, device='cuda', dtype=torch.int32)
+    rc = lib.tmf_topk_stable_f32(tm.lib.ptr(x), 8, 8, 8, 9, 0, tm.lib.ptr(out), None, s)        # k > cols
+    assert rc == -1 and b'k=9' in lib.tmf_last_error()
+    rc = lib.tmf_predict_topk_f32(tm.lib.ptr(x), tm.lib.ptr(x), 8, 8, 8, 8, 8, 33, 0, tm.lib.ptr(out), None, s)  # k > 32
+    assert rc == -1 or rc == -3
+    big = torch.zeros(4, 132, device='cuda')
+    rc = lib.tmf_predict_topk_f32(tm.lib.ptr(big), tm.lib.ptr(big), 4, 4, 130, 132, 132, 2, 0, tm.lib.ptr(out), None, s)
+    assert rc == -3 and b'n_components <= 128' in lib.tmf_last_error()                            # unsupported width
+    rc = lib.tmf_predict_gemm_f32(None, tm.lib.ptr(x), tm.lib.ptr(x), 8, 8, 8, 8, 8, 8, s)
+    assert rc == -1
+    seg = tm.lib.Segments(0, 0, 0, 0, 5, 1024, 0)                                                 # null arrays, nseg = 5
+    rc = lib.tmf_mse_pass_f32(ctypes.byref(seg), None, None, tm.lib.ptr(x), tm.lib.ptr(x), tm.lib.ptr(x), None, None, 8, 0,
+                              adam, s)
+    assert rc == -1 and b'segments' in lib.tmf_last_error()
+    rc = lib.tmf_adam_fresh_rows_f32(tm.lib.ptr(x), tm.lib.ptr(x), 8, 5000, adam, s)              # rank out of range
+    assert rc == -1
+    assert lib.tmf_padded_ld(5000) == 0 and lib.tmf_wmrb_user_workspace_bytes(10, 100, 8) == 0
+    assert lib.tmf_wmrb_user_workspace_bytes(10, 40000, 8) == 10 * 40000 * 4
+    with pytest.raises(tm.lib.EngineError):
+        tm.lib.check(rc, lib)
+    torch.cuda.synchronize()
+
+
 def test_wmrb_without_sample_table_raises(tm):
     model = tm.MF(3, loss_graph=tm.WMRB(), n_users=5, n_items=6)
     with pytest.raises(AttributeError):
