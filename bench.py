@@ -234,7 +234,8 @@ def main():
     U0 = init_table(m, r, 11 + rank, dev)
     V0 = torch.zeros(n_pad, r, device=dev)
     V0[:n] = init_table(n, r, 7, dev)  # identical on every rank
-    plan = _engine.InteractionPlan(idx, val, m, n_pad, user_chunks=_engine.mse_user_chunks())
+    plan = _engine.InteractionPlan(idx, val, m, n_pad, user_chunks=_engine.mse_user_chunks() if args.loss == 'mse' else 1,
+                                   csc=args.loss == 'mse')
     wplan, R = None, None
     if args.loss == 'wmrb':
         R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)

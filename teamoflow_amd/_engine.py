@@ -75,7 +75,7 @@ class SegmentTable:
 class InteractionPlan:
     """CSR-by-user and CSC-by-item views of the interactions (values duplicated in both orders)."""
 
-    def __init__(self, indices, values, n_users, n_items, chunk=DEFAULT_CHUNK, user_chunks=1):
+    def __init__(self, indices, values, n_users, n_items, chunk=DEFAULT_CHUNK, user_chunks=1, csc=True):
         dev = indices.device
         u = indices[:, 0].contiguous()
         j = indices[:, 1].contiguous()
@@ -90,26 +90,27 @@ class InteractionPlan:
         self.rowptr_u = _excl_cumsum(torch.bincount(u, minlength=n_users))
         self.col_u = j.to(torch.int32)
         self.val_u = values.contiguous()
-        # CSC by item; with user_chunks = C > 1 by (user block, item), blocks outermost, so that the U rows the
-        # item pass gathers at any time come from one cache-sized block of users (same idea as WmrbPlan)
+        self.seg_u = SegmentTable(self.rowptr_u, chunk)
+        # CSC by item (only the MSE item pass reads it); with user_chunks = C > 1 by (user block, item), blocks
+        # outermost, so that the U rows gathered at any time come from one cache-sized block of users
         C = max(1, int(user_chunks))
         self.user_chunks = C
-        if C > 1:
-            upc = -(-n_users // C)
-            key = (u // upc) * n_items + j
-        else:
-            key = j
-        perm_c = torch.sort(key, stable=True)[1]
-        self.rowptr_i = _excl_cumsum(torch.bincount(key, minlength=C * n_items))
-        self.row_i = u[perm_c].to(torch.int32)
-        self.val_i = values[perm_c].contiguous()
-        self.csc_to_csr = perm_c
-        self.seg_u = SegmentTable(self.rowptr_u, chunk)
-        if C > 1:
-            out_row = torch.arange(C * n_items, device=dev) % n_items
-            self.seg_i = SegmentTable(self.rowptr_i, chunk, out_row=out_row, n_out=n_items, row_mod=n_items)
-        else:
-            self.seg_i = SegmentTable(self.rowptr_i, chunk)
+        self.seg_i = self.rowptr_i = self.row_i = self.val_i = None
+        if csc:
+            if C > 1:
+                upc = -(-n_users // C)
+                key = (u // upc) * n_items + j
+            else:
+                key = j
+            perm_c = torch.sort(key, stable=True)[1]
+            self.rowptr_i = _excl_cumsum(torch.bincount(key, minlength=C * n_items))
+            self.row_i = u[perm_c].to(torch.int32)
+            self.val_i = values[perm_c].contiguous()
+            if C > 1:
+                out_row = torch.arange(C * n_items, device=dev) % n_items
+                self.seg_i = SegmentTable(self.rowptr_i, chunk, out_row=out_row, n_out=n_items, row_mod=n_items)
+            else:
+                self.seg_i = SegmentTable(self.rowptr_i, chunk)
         self.n_pos = int((values > 0).sum())
         self.user_ids = u  # int64, CSR order (kept for the WMRB entry lists)
 
@@ -244,7 +245,7 @@ class TrainState:
         self.U_nxt = torch.empty_like(self.U)
         self.V_nxt = torch.empty_like(self.V)
         self.plan, self.wplan = plan, wplan
-        n_slab = max(plan.seg_u.n_slab, plan.seg_i.n_slab, wplan.seg_e.n_slab if wplan else 0, 1)
+        n_slab = max(plan.seg_u.n_slab, plan.seg_i.n_slab if plan.seg_i else 0, wplan.seg_e.n_slab if wplan else 0, 1)
         self.slab = torch.empty(n_slab, self.ld, dtype=torch.float32, device=dev)
         n_part = max(plan.seg_u.nseg, plan.n_users, 1)
         self.loss_part = torch.zeros(n_part, dtype=torch.float32, device=dev)

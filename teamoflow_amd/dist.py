@@ -127,7 +127,7 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
     idx[:, 0] -= b
     val = interactions.values[keep]
     n_pad = padded_rows(n_items, world)
-    plan = _engine.InteractionPlan(idx, val, e - b, n_pad)
+    plan = _engine.InteractionPlan(idx, val, e - b, n_pad, csc=not wmrb)
     ld = _lib.padded_ld(model.n_components, model.factor_dtype)
     wplan, c = None, 0.0
     if wmrb:

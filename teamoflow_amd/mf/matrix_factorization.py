@@ -129,7 +129,7 @@ class MatrixFactorization:
             return
         ld = _lib.padded_ld(self.n_components, self.factor_dtype)
         plan = _engine.InteractionPlan(interactions.indices, interactions.values, n_users, n_items,
-                                       user_chunks=_engine.mse_user_chunks())
+                                       user_chunks=1 if wmrb else _engine.mse_user_chunks(), csc=not wmrb)
         wplan, c = None, 0.0
         if wmrb:
             if self.random_ind is None:
