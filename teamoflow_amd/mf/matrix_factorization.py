@@ -170,14 +170,22 @@ class MatrixFactorization:
                 for e in range(G):
                     run_epoch(e, block[e:e + 1])
             # capture only records; the tables are still the initial ones (G is even: buffers line up again)
+            t_prev = timeit.default_timer() - t0
             while done + G <= epochs:
                 graph.replay()
                 loss_sums[done:done + G].copy_(block)
                 done += G
                 if self.verbose and denom:
+                    t_now = None
                     for e in range(done - G, done):
                         if (e + 1) % 25 == 0:
-                            self._report(e, float(loss_sums[e]) / denom, (timeit.default_timer() - t0) * (e + 1) / done)
+                            if t_now is None:
+                                float(loss_sums[e])  # syncs: the replay has finished
+                                t_now = timeit.default_timer() - t0
+                            # cumulative runtime at epoch e, interpolated inside this replay
+                            self._report(e, float(loss_sums[e]) / denom, t_prev + (t_now - t_prev) * (e + 1 - (done - G)) / G)
+                    if t_now is not None:
+                        t_prev = t_now
         for epoch in range(done, epochs):
             run_epoch(epoch, loss_sums[epoch:epoch + 1])
             if self.verbose and (epoch + 1) % 25 == 0:

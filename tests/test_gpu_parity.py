@@ -600,6 +600,21 @@ def test_c_abi_error_codes_and_messages(tm):
     torch.cuda.synchronize()
 
 
+def test_example_script_runs_both_branches(tm, capsys):
+    """examples/toydata.py = the reference's toy benchmark call sequence through the `teamoflow` alias package."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('toydata', os.path.join(os.path.dirname(GOLDEN), '..', 'examples', 'toydata.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    np.random.seed(5)
+    m = mod.main('mse', 100, 50, 5)
+    assert len(m.loss_history_) == 450 and m.loss_history_[-1] < m.loss_history_[0]
+    w = mod.main('wmrb', 60, 40, 3)
+    assert len(w.loss_history_) == 100 and tuple(w.random_ind.shape) == (60, 20)
+    out = capsys.readouterr().out
+    assert 'Epoch 450 Complete | Loss' in out and 'Recall @ 10 w/ WMRB' in out and 'NDCG @ 10' in out
+
+
 def test_wmrb_without_sample_table_raises(tm):
     model = tm.MF(3, loss_graph=tm.WMRB(), n_users=5, n_items=6)
     with pytest.raises(AttributeError):
