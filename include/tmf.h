@@ -124,16 +124,6 @@ size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int n_component
  *   tmf_wmrb_finish_*   U_out[u] = epilogue(gpos[u] + sum_slice part[slice][u])
  * sp [n_users, S], gpos [n_users, ld], part are caller-provided fp32 scratch. */
 
-/* Experiment: the hinge arithmetic overlapped inside the scores launch: one launch computes the scores slice-major over super-batches of `superbatch_users`
- * users (0 = 65536) and, per group of 128 users, the workgroup that publishes the group's last slice runs
- * the hinge step for those users (agent-scope release / acquire through `counters`, int32 [ceil(n_users/128)],
- * zeroed by the call).  Then tmf_wmrb_gradu2_f32 and tmf_wmrb_finish_f32.  Slower than the separate kernels at C4
- * (too few hinge executors in flight), kept for the record. */
-int tmf_wmrb_scores_hinge_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                              int32_t n_users, int32_t S, int32_t superbatch_users, const float* U,
-                              const float* V, float* sp, const int64_t* rowptr, const int32_t* col,
-                              const float* val, float c, float* gpos, float* delta, float* D,
-                              float* loss_part, int32_t* counters, int n_components, void* stream);
 /* Staged sliced pass (the default for catalogs larger than two slices) - tables are float (_f32) or bf16
  * (_bf16) rows, passed as void*; sp / gpos / part / D / delta stay fp32.
  * gradu2: per_slice_launches = 0 -> one launch, part is [n_slices * n_users, ld] and finish gets n_slices;

@@ -261,7 +261,6 @@ class TrainState:
             # gradU partials: one layer per slice, or (above PART_BUDGET bytes) a single layer summed by per-slice launches
             self.part_layers = wplan.n_slices if wplan.n_slices * m * self.ld * 4 <= PART_BUDGET else 1
             self.part = torch.empty(self.part_layers * m, self.ld, dtype=torch.float32, device=dev)
-            self.counters = torch.zeros((m + 127) // 128, dtype=torch.int32, device=dev)
 
     def _pad(self, W, dev):
         W = torch.as_tensor(W).detach().to(device=dev, dtype=torch.float32)
@@ -330,34 +329,21 @@ def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=No
 
 def _wmrb_user_pass_sliced(lib, st, adam, c):
     """Sliced user pass: scores -> hinge -> gradU -> finish (see csrc/tmf_wmrb.hip)."""
-    p, w, r, ld = st.plan, st.wplan, st.r, st.ld
+    p, w, r = st.plan, st.wplan, st.r
     i32 = ctypes.c_int32
     m, S, ns = p.n_users, w.S, w.n_slices
-    mode = os.environ.get('TMF_SLICED_MODE', 'staged')
-    if st.dtype is not torch.float32 and mode != 'staged':
-        raise ValueError('only the staged sliced pass supports bf16 tables')
-    if mode in ('staged', 'ticket'):
-        s = _lib.stream_ptr()
-        if mode == 'ticket':
-            # one launch: scores + (last arriver per 128-user group) hinge
-            sb = int(os.environ.get('TMF_SUPERBATCH_USERS', '65536'))
-            _lib.check(lib.tmf_wmrb_scores_hinge_f32(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), i32(sb),
-                                                     _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp), _lib.ptr(p.rowptr_u),
-                                                     _lib.ptr(p.col_u), _lib.ptr(p.val_u), c, _lib.ptr(st.gpos),
-                                                     _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part),
-                                                     _lib.ptr(st.counters), r, s), lib)
-        else:
-            _lib.check(getattr(lib, 'tmf_wmrb_scores2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(st.U),
-                                                _lib.ptr(st.V), _lib.ptr(st.sp), r, s), lib)
-            _lib.check(getattr(lib, 'tmf_wmrb_hinge' + st.sfx)(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.sp),
-                                              i32(m), i32(S), c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.gpos),
-                                              _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), r, s), lib)
-        _lib.check(getattr(lib, 'tmf_wmrb_gradu2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S), _lib.ptr(w.D),
-                                           _lib.ptr(st.V), _lib.ptr(st.part), int(st.part_layers == 1 and ns > 1), r, s), lib)
-        _lib.check(getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.gpos), _lib.ptr(st.part), i32(st.part_layers), i32(m),
-                                                            _lib.ptr(st.U), _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s), lib)
-        return
-    raise ValueError(f'unknown TMF_SLICED_MODE={mode!r}')
+    s = _lib.stream_ptr()
+    _lib.check(getattr(lib, 'tmf_wmrb_scores2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S),
+                                                         _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp), r, s), lib)
+    _lib.check(getattr(lib, 'tmf_wmrb_hinge' + st.sfx)(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u),
+                                                       _lib.ptr(st.sp), i32(m), i32(S), c, _lib.ptr(st.U), _lib.ptr(st.V),
+                                                       _lib.ptr(st.gpos), _lib.ptr(w.delta), _lib.ptr(w.D),
+                                                       _lib.ptr(st.loss_part), r, s), lib)
+    _lib.check(getattr(lib, 'tmf_wmrb_gradu2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S),
+                                                        _lib.ptr(w.D), _lib.ptr(st.V), _lib.ptr(st.part),
+                                                        int(st.part_layers == 1 and ns > 1), r, s), lib)
+    _lib.check(getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.gpos), _lib.ptr(st.part), i32(st.part_layers), i32(m),
+                                                        _lib.ptr(st.U), _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s), lib)
 
 
 def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):

@@ -54,8 +54,6 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_user_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, _I]),
     'tmf_wmrb_hinge_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_finish_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _I, _I, Adam, _P]),
-    'tmf_wmrb_scores_hinge_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P,
-                                        _P, _F, _P, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_scores2_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
     'tmf_wmrb_gradu2_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _I, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),

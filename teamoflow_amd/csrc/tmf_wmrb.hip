@@ -349,14 +349,9 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 constexpr int kSliceUsers = 128;  // users per workgroup of k_wmrb_slice
 
 // ---------------------------------------------------------------------------------------------
-// Experiment (TMF_SLICED_MODE=ticket): k_wmrb_scores_hinge = the scores kernel + the hinge kernel in ONE launch: users are walked in super-batches, slice-major
-// inside a super-batch; every (slice, user-group) workgroup publishes its scores and takes a ticket on
-// the group's counter, and the workgroup that draws the last ticket runs the hinge arithmetic for the
-// group's 128 users - beside the next super-batch's gathers, which is the overlap the fused kernel gets
-// between workgroups.  Hand-off = the counter form of the agent-scope release/acquire recipe
-// (cdna_hip_programming.md §6 Guideline 16): stores -> every wave's vmcnt(0) -> barrier -> lane 0 release
-// fence -> vmcnt(0) -> relaxed agent fetch_add; last arriver: acquire fence -> vmcnt(0) -> barrier -> plain
-// loads.  Counters are zeroed by a memset node before every launch.  Placement-independent.
+// (An in-launch variant - scores + hinge in one launch, the workgroup publishing a 128-user group's last slice
+// running the hinge step behind an agent-scope release/acquire ticket - was measured slower, 93 ms against
+// 46 + 40 ms for the pair, and removed; see profiles/r01_sliced_user_pass.txt.)
 // Both slice roles stage the (user, slice) range's item ids (and D) through LDS so that a row gather
 // depends on an LDS read only.
 // ---------------------------------------------------------------------------------------------
@@ -435,49 +430,6 @@ __device__ __forceinline__ void wmrb_slice_body(
                 store_row_f32<G, NV, T>(acc, part, u - part_u0, g);
             }
         }
-    }
-}
-
-// grid = n_superbatches * n_slices * groups_per_sb; block -> (super-batch, slice, group in super-batch)
-template <int G, int NV, typename T>
-__global__ __launch_bounds__(kThreads) void k_wmrb_scores_hinge(
-    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
-    int64_t groups_per_sb, int64_t n_groups, const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp,
-    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, float c,
-    float* __restrict__ gpos, float* __restrict__ delta, float* __restrict__ Dg, float* __restrict__ loss_part,
-    int* __restrict__ counters) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int64_t per_sb = groups_per_sb * n_slices;
-    const int64_t sb = blockIdx.x / per_sb, rem = blockIdx.x % per_sb;
-    const int64_t sl = rem / groups_per_sb, grp = sb * groups_per_sb + rem % groups_per_sb;
-    if (grp >= n_groups) return;  // block-uniform
-    const int64_t ubeg = grp * kSliceUsers;
-    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
-    wmrb_slice_body<G, NV, T, false>(smem_raw, sl, ubeg, uend, R, off, n_slices, 0, 0, S, U, V, sp, nullptr, nullptr);
-
-    // publish this block's scores and take a ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem_raw);
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        flag[0] = __hip_atomic_fetch_add(&counters[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const bool last = flag[0] == n_slices - 1;  // block-uniform
-    __syncthreads();                            // everyone has read the flag before LDS is reused
-    if (!last) return;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    const tmf_adam none = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t u = ubeg; u < uend; ++u) {
-        wmrb_user_body<G, NV, T, true, false>(u, smem_raw, rowptr, col, val, nullptr, sp, nullptr, S, c, U, V, gpos, delta, Dg,
-                                              loss_part, nullptr, TMF_EPI_GRAD, none);
-        __syncthreads();
     }
 }
 
@@ -575,38 +527,6 @@ extern "C" int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col
 
 
 
-extern "C" int tmf_wmrb_scores_hinge_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                                         int32_t n_users, int32_t S, int32_t superbatch_users, const float* U,
-                                         const float* V, float* sp, const int64_t* rowptr, const int32_t* col,
-                                         const float* val, float c, float* gpos, float* delta, float* D,
-                                         float* loss_part, int32_t* counters, int n_components, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(R_sorted && slice_off && U && V && sp && rowptr && gpos && D && counters && n_slices > 0 && S > 0,
-                "wmrb_scores_hinge: bad arguments");
-    const RowGeom geom = row_geom(n_components);
-    const int64_t n_groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
-    int64_t gps = ((int64_t)(superbatch_users > 0 ? superbatch_users : 65536) + kSliceUsers - 1) / kSliceUsers;
-    if (gps > n_groups) gps = n_groups;
-    const int64_t n_sb = (n_groups + gps - 1) / gps;
-    const int64_t blocks = n_sb * gps * n_slices;
-    TMF_REQUIRE(blocks < ((int64_t)1 << 31), "wmrb_scores_hinge: grid too large");
-    size_t lds = wmrb_user_lds(S, geom.ld, false, true);
-    const size_t stage = (size_t)(64 / geom.G) * kWaves * 2 * 8 * geom.G * sizeof(int);
-    if (stage > lds) lds = stage;
-    if (lds > 64 * 1024) {
-        set_error("wmrb_scores_hinge: n_samples=%d needs %zu bytes of LDS; use the fused pass", S, lds);
-        return TMF_E_UNSUPPORTED;
-    }
-    hipError_t e = hipMemsetAsync(counters, 0, (size_t)n_groups * sizeof(int32_t), (hipStream_t)stream);
-    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return TMF_E_LAUNCH; }
-#define CALL(G_, NV_)                                                                                                \
-    hipLaunchKernelGGL((k_wmrb_scores_hinge<G_, NV_, float>), dim3((unsigned)blocks), dim3(kThreads), lds,            \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, gps, n_groups, U, \
-                       V, sp, rowptr, col, val, c, gpos, delta, D, loss_part, counters)
-    TMF_DISPATCH_GEOM(geom, CALL);
-#undef CALL
-    return check_launch("tmf_wmrb_scores_hinge_f32");
-}
 
 
 

@@ -219,14 +219,11 @@ def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
     assert rel_err(chunked.loss_history_, base.loss_history_) < 1e-6
 
 
-@pytest.mark.parametrize('mode', ['staged', 'ticket'])
 @pytest.mark.parametrize('slices', ['2', '5', '64'])
-def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, mode):
-    """TMF_ITEM_SLICES > 1: the sliced user pass instead of the fused one - four kernels (staged, default) or
-    scores+hinge in one launch with the last-arriver hand-off (ticket); also with per-slice gradU launches."""
+def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices):
+    """TMF_ITEM_SLICES > 1: the sliced user pass (scores / hinge / gradU / finish) instead of the fused kernel;
+    also with per-slice gradU launches."""
     monkeypatch.setenv('TMF_ITEM_SLICES', slices)
-    monkeypatch.setenv('TMF_SUPERBATCH_USERS', '256')
-    monkeypatch.setenv('TMF_SLICED_MODE', mode)
     if slices == '5':
         monkeypatch.setattr(tm.engine, 'PART_BUDGET', 0)  # memory-light gradU: one launch per slice
     for name in ('wmrb_small', 'wmrb_mixed'):
