@@ -76,6 +76,24 @@ typedef struct tmf_segments {
                         block * n_rows + table row (every segment then owns a slab slot) */
 } tmf_segments;
 
+/* Index preparation, once per fit() (there is no counterpart in the reference: it gathers from the dense
+ * [m, n] score matrix with SparseTensor.indices, loss_graphs.py:47-50; these views are what lets the passes stream).
+ *   tmf_csr_build: COO (indices [nnz, 2] int64 row-major pairs in any order, values [nnz]) -> CSR by user with the
+ *     original order kept inside a user (stable): rowptr_u [n_users + 1], col_u / val_u / user_of [nnz].
+ *   tmf_csc_perm:  stable order of the CSR entries by item: perm [nnz] (CSR positions), rowptr_i [n_items + 1].
+ *   tmf_stable_order_i32: the building block - stable radix sort of int32 keys in [0, n_rows) with their positions,
+ *     plus rowptr[r] = first sorted position with key >= r.  sorted_keys may be NULL.
+ * workspace: caller-provided device scratch of at least the matching *_workspace_bytes(). */
+size_t tmf_csr_build_workspace_bytes(int64_t nnz);
+int tmf_csr_build(const int64_t* indices, const float* values, int64_t nnz, int32_t n_users,
+                  int64_t* rowptr_u, int32_t* col_u, float* val_u, int32_t* user_of, void* workspace,
+                  size_t workspace_bytes, void* stream);
+size_t tmf_stable_order_workspace_bytes(int64_t n);
+int tmf_csc_perm(const int32_t* col_u, int64_t nnz, int32_t n_items, int64_t* rowptr_i, int64_t* perm,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int tmf_stable_order_i32(const int32_t* keys, int64_t n, int64_t n_rows, int64_t* perm, int32_t* sorted_keys,
+                         int64_t* rowptr, void* workspace, size_t workspace_bytes, void* stream);
+
 /* K1+K2 / K3: one side of an MSE epoch (loss_graphs.py:47-52 forward; tape.gradient
  * matrix_factorization.py:170-171; Adam :176) evaluated sparsely:
  *   for every entry k of row i:  p = <X_old[i], Y_old[other[k]]>, e = val[k] - p,

@@ -23,6 +23,24 @@ def _excl_cumsum(x):
     return out
 
 
+def stable_order(keys, n_rows):
+    """(perm, rowptr): stable order of int keys in [0, n_rows) and the row pointers of the sorted list.
+    Device tensors go through libtmf (tmf_stable_order_i32: rocPRIM radix sort + binary-search row pointers);
+    CPU tensors (host-logic tests) through torch."""
+    n = keys.numel()
+    if keys.is_cuda and n < 2 ** 31 and n_rows < 2 ** 31:
+        lib = _lib.get()
+        k32 = keys.to(torch.int32).contiguous()
+        perm = torch.empty(n, dtype=torch.int64, device=keys.device)
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=keys.device)
+        ws = torch.empty(lib.tmf_stable_order_workspace_bytes(n), dtype=torch.uint8, device=keys.device)
+        _lib.check(lib.tmf_stable_order_i32(_lib.ptr(k32), n, n_rows, _lib.ptr(perm), None, _lib.ptr(rowptr), _lib.ptr(ws),
+                                            ws.numel(), _lib.stream_ptr()), lib)
+        return perm, rowptr
+    perm = torch.sort(keys, stable=True)[1]
+    return perm, _excl_cumsum(torch.bincount(keys.to(torch.int64), minlength=n_rows))
+
+
 class SegmentTable:
     """Rows of one side cut into segments of <= chunk entries (see include/tmf.h, tmf_segments).
 
@@ -82,14 +100,29 @@ class InteractionPlan:
         nnz = u.numel()
         if nnz and (int(u.min()) < 0 or int(u.max()) >= n_users or int(j.min()) < 0 or int(j.max()) >= n_items):
             raise IndexError('interaction indices outside dense_shape')
-        values = values.to(torch.float32)
-        if nnz > 1 and not bool((u[1:] >= u[:-1]).all()):
-            perm = torch.sort(u, stable=True)[1]
-            u, j, values = u[perm], j[perm], values[perm]
+        values = values.to(torch.float32).contiguous()
         self.nnz, self.n_users, self.n_items = nnz, n_users, n_items
-        self.rowptr_u = _excl_cumsum(torch.bincount(u, minlength=n_users))
-        self.col_u = j.to(torch.int32)
-        self.val_u = values.contiguous()
+        if indices.is_cuda and nnz < 2 ** 31:
+            # native: stable sort by user, gather columns / values, row pointers (tmf_csr_build)
+            lib = _lib.get()
+            idx64 = indices.to(torch.int64).contiguous()
+            self.rowptr_u = torch.empty(n_users + 1, dtype=torch.int64, device=dev)
+            self.col_u = torch.empty(nnz, dtype=torch.int32, device=dev)
+            self.val_u = torch.empty(nnz, dtype=torch.float32, device=dev)
+            user_of = torch.empty(nnz, dtype=torch.int32, device=dev)
+            ws = torch.empty(lib.tmf_csr_build_workspace_bytes(nnz), dtype=torch.uint8, device=dev)
+            _lib.check(lib.tmf_csr_build(_lib.ptr(idx64), _lib.ptr(values), nnz, n_users, _lib.ptr(self.rowptr_u),
+                                         _lib.ptr(self.col_u), _lib.ptr(self.val_u), _lib.ptr(user_of), _lib.ptr(ws),
+                                         ws.numel(), _lib.stream_ptr()), lib)
+            u, j, values = user_of.to(torch.int64), self.col_u.to(torch.int64), self.val_u
+            del ws, idx64
+        else:
+            if nnz > 1 and not bool((u[1:] >= u[:-1]).all()):
+                perm = torch.sort(u, stable=True)[1]
+                u, j, values = u[perm], j[perm], values[perm]
+            self.rowptr_u = _excl_cumsum(torch.bincount(u, minlength=n_users))
+            self.col_u = j.to(torch.int32)
+            self.val_u = values.contiguous()
         self.seg_u = SegmentTable(self.rowptr_u, chunk)
         # CSC by item (only the MSE item pass reads it); with user_chunks = C > 1 by (user block, item), blocks
         # outermost, so that the U rows gathered at any time come from one cache-sized block of users
@@ -102,8 +135,7 @@ class InteractionPlan:
                 key = (u // upc) * n_items + j
             else:
                 key = j
-            perm_c = torch.sort(key, stable=True)[1]
-            self.rowptr_i = _excl_cumsum(torch.bincount(key, minlength=C * n_items))
+            perm_c, self.rowptr_i = stable_order(key, C * n_items)
             self.row_i = u[perm_c].to(torch.int32)
             self.val_i = values[perm_c].contiguous()
             if C > 1:
@@ -192,12 +224,9 @@ class WmrbPlan:
         if C > 1:
             keys_pos = keys_pos + (pos_u // upc) * n
             keys_smp = keys_smp + (torch.arange(m, device=dev) // upc).repeat_interleave(S) * n
-        counts = torch.bincount(keys_pos, minlength=C * n) + torch.bincount(keys_smp, minlength=C * n)
         keys = torch.cat([keys_pos, keys_smp])
         del keys_pos, keys_smp
-        if C * n < 2 ** 31:
-            keys = keys.to(torch.int32)
-        order = torch.sort(keys, stable=True)[1]
+        order, self.rowptr_e = stable_order(keys, C * n)
         del keys
         is_pos = order < P
         e = order - P  # sample entry id u * S + s (negative for positives, unused there)
@@ -210,7 +239,6 @@ class WmrbPlan:
         self.S, self.R, self.user_chunks = S, R, C
         self.ent_row = ent_row.to(torch.int32).contiguous()
         self.ent_w = ent_w.to(torch.int64).contiguous()
-        self.rowptr_e = _excl_cumsum(counts)
         if C > 1:
             out_row = torch.arange(C * n, device=dev) % n
             self.seg_e = SegmentTable(self.rowptr_e, chunk, out_row=out_row, n_out=n)

@@ -46,6 +46,11 @@ _BASE_SIGNATURES = {
     'tmf_padded_ld': (_I, [_I]),
     'tmf_padded_ld_bf16': (_I, [_I]),
     'tmf_adam_fresh': (Adam, [_F]),
+    'tmf_csr_build_workspace_bytes': (ctypes.c_size_t, [_L]),
+    'tmf_csr_build': (_I, [_P, _P, _L, ctypes.c_int32, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    'tmf_stable_order_workspace_bytes': (ctypes.c_size_t, [_L]),
+    'tmf_csc_perm': (_I, [_P, _L, ctypes.c_int32, _P, _P, _P, ctypes.c_size_t, _P]),
+    'tmf_stable_order_i32': (_I, [_P, _L, _L, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     'tmf_mse_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),

@@ -567,6 +567,29 @@ def test_randomized_shapes_against_oracle(tm, monkeypatch, seed):
         assert rel_err(pred, sc) < 1e-5
 
 
+def test_native_index_prep_equals_torch_prep(tm):
+    """tmf_csr_build / tmf_stable_order_i32 (device path of the plans) against the torch ops the CPU path uses."""
+    rng = np.random.default_rng(8)
+    for m, n, nnz, S_, chunks in [(40, 30, 500, 7, 1), (1000, 777, 50000, 16, 5), (5, 9, 0, 3, 2), (300, 4000, 20000, 64, 3)]:
+        idx = np.stack([rng.integers(0, m, nnz), rng.integers(0, n, nnz)], axis=1).reshape(-1, 2)
+        val = rng.integers(-1, 5, nnz).astype(np.float32)
+        R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)]).astype(np.int32)
+        plans = []
+        for dev in ('cpu', 'cuda'):
+            p = tm.engine.InteractionPlan(torch.tensor(idx, device=dev), torch.tensor(val, device=dev), m, n, chunk=64,
+                                          user_chunks=chunks)
+            w = tm.engine.WmrbPlan(p, torch.tensor(R, device=dev), chunk=64, user_chunks=chunks, item_slices=3)
+            plans.append((p, w))
+        (pc, wc), (pg, wg) = plans
+        for name in ('rowptr_u', 'col_u', 'val_u', 'rowptr_i', 'row_i', 'val_i', 'user_ids'):
+            assert torch.equal(getattr(pc, name), getattr(pg, name).cpu()), (name, m, n, nnz)
+        for name in ('ent_row', 'ent_w', 'rowptr_e', 'R', 'slice_off'):
+            assert torch.equal(getattr(wc, name), getattr(wg, name).cpu()), (name, m, n, nnz)
+        for seg_c, seg_g in ((pc.seg_u, pg.seg_u), (pc.seg_i, pg.seg_i), (wc.seg_e, wg.seg_e)):
+            for name in ('seg_row', 'seg_chunk', 'seg_slab', 'long_rows', 'long_slab_beg'):
+                assert torch.equal(getattr(seg_c, name), getattr(seg_g, name).cpu()), name
+
+
 def test_c_abi_error_codes_and_messages(tm):
     """Bad arguments come back as negative codes with a message, never as a launch on bad pointers."""
     import ctypes
