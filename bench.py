@@ -142,7 +142,7 @@ def host_cores():
     return min(n, 16) if n > 64 else n
 
 
-def small_configs(dev):
+def small_configs(dev, quick=False):
     """BASELINE configs 1-3 (CPU-runnable shapes): fit() wall time on the GPU (hipGraph-replayed epochs)
     next to the dense-faithful CPU restatement of the reference formulation (oracle/dense_ref.py: identity
     feature matmuls, [m, n] scores, autograd, fresh Adam) timed over the same region the reference times."""
@@ -156,6 +156,8 @@ def small_configs(dev):
     cases = [('C1', 100, 50, 5, 0.05, 'mse', 1e-2, 450, 450, None),
              ('C2', 943, 1682, 32, 100000 / (0.9 * 943 * 1682), 'mse', 1e-3, 100, 100, None),
              ('C3', 6040, 3706, 64, 1000209 / (0.9 * 6040 * 3706), 'wmrb', 0.1, 100, 2, 3706 // 2)]
+    if quick:  # default bench run: C2 in full, one dense CPU epoch of C3 (~10 s of CPU work in all)
+        cases = [cases[1], cases[2][:8] + (1,) + cases[2][9:]]
     for name, m, n, r, density, loss, lr, epochs, cpu_epochs, S in cases:
         np.random.seed(0)
         idx, val, shape, A = G.generate_random_interaction(m, n, density=density)
@@ -352,8 +354,9 @@ def main():
                                   else '(tmf_predict_topk_f32: exact-fp32 MFMA, peak 157.3 TF)'))
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want), case='C1 golden fixture')
-    if rank == 0 and world == 1 and args.small_configs:
-        out['small_configs'] = small_configs(dev)
+    if rank == 0 and world == 1 and (args.small_configs or not args.no_extras):
+        # the reference's own (dense, full-batch) formulation on the host cores next to the engine, BASELINE configs 1-3
+        out['reference_formulation_cpu'] = small_configs(dev, quick=not args.small_configs)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dp_mode:
