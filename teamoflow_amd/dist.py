@@ -10,7 +10,7 @@ row-sharded for the optimiser:
     reduce-scatter(sum)  RCCL over xGMI                      gV_shard   [n_pad / G, ld]
     fresh-Adam           local (HIP) on the owned V rows     the step is non-linear in g, so the sum
                                                              must complete before any update
-    all-gather           RCCL, in place                      V [n_pad, ld] replicated again
+    all-gather           RCCL                                V [n_pad, ld] replicated again
     all-reduce           2 doubles                           (sum of losses, count)
 
 The compute is injected (``backend``) so the choreography can be exercised with gloo on CPU
@@ -88,6 +88,7 @@ class DataParallelEpoch:
         self.rows_per_rank = V.shape[0] // self.world
         self.g_shard = torch.empty(self.rows_per_rank, V.shape[1], dtype=torch.float32, device=V.device)
         self.stats = torch.zeros(2, dtype=torch.float64, device=V.device)
+        self.V_gather = torch.empty_like(V)  # all-gather target (kept separate from its input shard: no aliasing)
         self.local_count = float(local_count)
 
     def step(self):
@@ -97,7 +98,8 @@ class DataParallelEpoch:
         V = self.b.V()
         mine = V[self.rank * self.rows_per_rank:(self.rank + 1) * self.rows_per_rank]
         self.b.adam_rows(mine, self.g_shard)
-        dist.all_gather_into_tensor(V, mine, group=self.group)
+        dist.all_gather_into_tensor(self.V_gather, mine.contiguous(), group=self.group)
+        V.copy_(self.V_gather)
         self.stats[0] = loss_sum.reshape(())
         self.stats[1] = self.local_count
         dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
