@@ -211,6 +211,13 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip cpu baseline / predict / mse side measurements')
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner at communicator
+    # creation) write to file descriptor 1 as well, so keep a private copy of stdout for the JSON line and point
+    # fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -358,7 +365,7 @@ def main():
         # the reference's own (dense, full-batch) formulation on the host cores next to the engine, BASELINE configs 1-3
         out['reference_formulation_cpu'] = small_configs(dev, quick=not args.small_configs)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dp_mode:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
