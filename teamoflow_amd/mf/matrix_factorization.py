@@ -10,6 +10,7 @@ own ``get_repr`` / ``get_loss``.
 """
 import os
 import timeit
+import warnings
 
 import numpy as np
 import torch
@@ -19,9 +20,10 @@ from .embedding_graphs import BiasedLinearEmbedding, Embeddings, LinearEmbedding
 from .initializer_graphs import NormalInitializer
 from .loss_graphs import KLDivergenceLoss, LossGraph, MSELoss, WMRBLoss
 from .sparse import IndicatorFeatures, SparseInteractions, default_device, is_indicator
-from .utils import gather_matrix_indices, random_sampler
+from .utils import gather_matrix_indices, random_sampler, random_sampler_device
 
 PREDICT_CHUNK_BYTES = 2 << 30  # users are scored in blocks of at most this many bytes of scores
+HOST_SAMPLER_MAX_WORK = 2_000_000_000  # n_users * n_items above which generate_sample=True samples on the device
 GRAPH_EPOCHS = 50              # epochs captured per hipGraph on launch-bound problems
 GRAPH_MAX_WORK = 20_000_000    # interactions + sampled scores per epoch below which fit() uses graphs
 
@@ -61,7 +63,14 @@ class MatrixFactorization:
         if n_samples is None and n_items is not None:  # :68-69
             self.n_samples = n_items // 2
         if generate_sample == True:  # noqa: E712  (:72-73; the table is drawn once and never resampled)
-            self.random_ind = random_sampler(n_items, n_users, self.n_samples)
+            if n_users * n_items > HOST_SAMPLER_MAX_WORK and torch.cuda.is_available():
+                # the reference's host loop (one O(n_items) np.random.choice per user) would take minutes here:
+                # draw the table on the device instead - same distribution, not the NumPy stream
+                warnings.warn(f'random_sampler: {n_users} users x {n_items} items is too large for the host loop; '
+                              'drawing the negative table on the device (utils.random_sampler_device)')
+                self.random_ind = random_sampler_device(n_items, n_users, self.n_samples)
+            else:
+                self.random_ind = random_sampler(n_items, n_users, self.n_samples)
 
         if isinstance(self.user_repr_graph, ReLUEmbedding):  # :76-79
             self.user_aux_dim = 5 * self.n_components
