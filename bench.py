@@ -38,21 +38,28 @@ def gen_interactions(m, n, nnz_target, items, seed, dev):
     """Synthetic interactions of SURVEY.md §8d: user degrees lognormal(4.2, 0.8) rescaled to the
     target; item ids from a power law (alpha = 1) over a fixed permutation ('zipf') or uniform;
     values in {1..5}; unique row-major pairs."""
-    g = torch.Generator(device=dev).manual_seed(1000 + seed)
-    deg = torch.exp(4.2 + 0.8 * torch.randn(m, device=dev, generator=g))
-    deg = torch.clamp(torch.round(deg * (nnz_target / float(deg.sum()))), 1, n // 4).to(torch.int64)
-    total = int(deg.sum())
-    u = torch.repeat_interleave(torch.arange(m, device=dev), deg, output_size=total)
-    if items == 'zipf':
-        x = torch.rand(total, device=dev, generator=g)
-        ranks = torch.clamp(torch.pow(float(n + 1), x).to(torch.int64) - 1, 0, n - 1)
-        perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(4242))
-        j = perm[ranks]
-        del x, ranks
-    else:
-        j = torch.randint(0, n, (total,), device=dev, generator=g)
-    key = torch.unique(u * n + j)
-    del u, j
+    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(4242))
+    inflate = 1.0
+    for attempt in range(4):
+        # duplicate (user, item) draws collapse (19 % of them at C4 with the power law), so the draw is repeated with
+        # an inflated target until the number of UNIQUE pairs is within 1 % of the requested nnz
+        g = torch.Generator(device=dev).manual_seed(1000 + seed)
+        deg = torch.exp(4.2 + 0.8 * torch.randn(m, device=dev, generator=g))
+        deg = torch.clamp(torch.round(deg * (nnz_target * inflate / float(deg.sum()))), 1, n // 4).to(torch.int64)
+        total = int(deg.sum())
+        u = torch.repeat_interleave(torch.arange(m, device=dev), deg, output_size=total)
+        if items == 'zipf':
+            x = torch.rand(total, device=dev, generator=g)
+            ranks = torch.clamp(torch.pow(float(n + 1), x).to(torch.int64) - 1, 0, n - 1)
+            j = perm[ranks]
+            del x, ranks
+        else:
+            j = torch.randint(0, n, (total,), device=dev, generator=g)
+        key = torch.unique(u * n + j)
+        del u, j
+        if key.numel() >= 0.99 * nnz_target:
+            break
+        inflate *= nnz_target / key.numel()
     u, j = key // n, key % n
     vals = torch.randint(1, 6, (key.numel(),), device=dev, generator=g).to(torch.float32)
     return torch.stack([u, j], dim=1), vals
@@ -75,22 +82,34 @@ def mse_bytes(m, n, nnz, r, s=4):
     return nnz * (r * s + 12) + m * 2 * r * s, nnz * (r * s + 12) + n * 2 * r * s
 
 
-def cpu_baseline_wmrb(idx, val, R, U0, V0, n, S, lr, users=1024):
-    """The oracle's closed-form WMRB epoch (oracle/sparse_ref.py, NumPy, 1 thread of BLAS-free code) on
-    the first `users` users of the same workload - a reported baseline, never the measured path."""
-    from oracle import sparse_ref
+def cpu_baseline(loss, idx, val, R, U0, V0, n, S, lr, users=None, epochs=3):
+    """The C/OpenMP closed-form epoch (oracle/sparse_ref.c - "sparse CPU restatement, not the reference
+    formulation") on the first `users` users of the same workload with every host core this
+    process may use.  A reported baseline, never the measured path."""
+    from oracle import sparse_c
+    cores = host_cores()
+    sparse_c.set_threads(cores)
+    users = min(users or (131072 if loss == 'wmrb' else 262144), int(U0.shape[0]))   # ~10-20 s of CPU work at C4 on 16 cores
     rows = idx[:, 0] < users
-    sidx = idx[rows].cpu().numpy()
-    sval = val[rows].cpu().numpy()
-    Us = U0[:users].cpu().numpy()
-    Vs = V0.cpu().numpy()
-    Rs = R[:users].cpu().numpy().astype(np.int64)
+    sidx, sval = idx[rows].cpu().numpy(), val[rows].cpu().numpy()
+    Us, Vs = U0[:users].cpu().numpy(), V0.cpu().numpy()
+    plan = sparse_c.Plan(sidx, sval, users, n, R[:users].cpu().numpy() if loss == 'wmrb' else None)
+
+    def epoch(Uc, Vc):
+        if loss == 'wmrb':
+            return sparse_c.wmrb_epoch(Uc, Vc, plan, n, S, lr, want_grads=False)[:2]
+        return sparse_c.mse_epoch(Uc, Vc, plan, lr, want_grads=False)[:2]
+
+    Uc, Vc = epoch(Us, Vs)  # warm-up (page faults, thread pool)
     t0 = time.perf_counter()
-    sparse_ref.wmrb_epoch(Us, Vs, sidx, sval, Rs, n, S, lr)
-    dt = time.perf_counter() - t0
-    return dict(value=len(sval) / dt, unit='interactions/s', cores=1, kind='port',
-                sample=f'one WMRB epoch of oracle/sparse_ref.py on the first {users} users of the same workload '
-                       f'({len(sval)} interactions, S={S}, r={Us.shape[1]}), {dt:.1f} s')
+    for _ in range(epochs):
+        Uc, Vc = epoch(Uc, Vc)
+    dt = (time.perf_counter() - t0) / epochs
+    return dict(value=len(sval) / dt, unit='interactions/s', cores=cores, kind='port',
+                sample=f'{epochs} {loss.upper()} epochs of oracle/sparse_ref.c (C, OpenMP, {cores} threads) on the first {users} '
+                       f'users of the same workload against all {n} items ({len(sval)} interactions'
+                       + (f', S={S}' if loss == 'wmrb' else '') + f', r={Us.shape[1]}), {dt:.2f} s per epoch; '
+                       'sparse closed-form restatement, not the reference\'s dense formulation (that one: reference_formulation_cpu)')
 
 
 def recall_parity(dev):
@@ -223,6 +242,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    # TMF_BENCH_REHEARSE=1: every rank on card 0 with a gloo group (dist.py stages the collectives through the host) -
+    # a functional rehearsal of the N>1 path on a one-GPU box; its timings mean nothing
+    rehearse = os.environ.get('TMF_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dp_mode = world > 1 or os.environ.get('TMF_BENCH_FORCE_DP') == '1'  # the env knob rehearses the N>1 path on one GPU
@@ -231,8 +255,11 @@ def main():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29577')
             torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        elif rehearse:
+            torch.distributed.init_process_group('gloo')
         else:
             torch.distributed.init_process_group('nccl', device_id=dev)
+    red_dev = 'cpu' if rehearse else dev   # where the two scalar reductions of the report live
     _lib.get()
 
     m, n, r, S = args.users, args.items, args.r, args.samples
@@ -292,10 +319,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dp_mode:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-        tot = torch.tensor([float(nnz)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(nnz)], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(tot)
         nnz_total = float(tot)
     else:
@@ -333,7 +360,7 @@ def main():
     out = dict(metric='train_interactions_per_sec', value=nnz_total / (elapsed / args.steps), unit='interactions/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                scaling='weak', vs_baseline=None, dtype='f32' if args.dtype == 'f32' else 'bf16 storage / f32 arithmetic',
-               data='synthetic',
+               data='synthetic' + (' (REHEARSAL: all ranks on one card, host-staged gloo collectives - timings invalid)' if rehearse else ''),
                config=dict(workload=f'C4: {m} users x {n} items per GPU, r={r}, {args.loss.upper()}'
                                     + (f' S={S}' if args.loss == 'wmrb' else '') + f', item ids {args.item_dist}, '
                                     f'lognormal user degrees', interactions_per_gpu=nnz, positives_per_gpu=plan.n_pos,
@@ -343,8 +370,7 @@ def main():
     if rank == 0 and not args.no_extras and world == 1:
         losses = loss_buf[:args.steps + args.warmup].cpu().numpy() / (plan.n_pos if args.loss == 'wmrb' else nnz)
         out['loss_first_last'] = [float(losses[0]), float(losses[-1])]
-        if args.loss == 'wmrb':
-            out['cpu_baseline'] = cpu_baseline_wmrb(idx, val, R, U0, V0[:n], n, S, args.lr)
+        out['cpu_baseline'] = cpu_baseline(args.loss, idx, val, R, U0, V0[:n], n, S, args.lr)
         # predict rows/s: stable top-10 over the full catalog, fused GEMM + top-k (no [m, n] matrix)
         Ue, Ve = st.U[:, :r], st.V[:n, :r]
         rows = min(m, 262144)

@@ -73,6 +73,40 @@ class HipBackend:
         self.st.U, self.st.U_nxt = self.st.U_nxt, self.st.U
 
 
+def _staged(group, t):
+    """gloo has no device collectives for every op used here: with a gloo group and device tensors the
+    collective runs on host copies (rehearsal of the N>1 path with several ranks on ONE card, where RCCL
+    refuses duplicate devices).  With RCCL - the production path - nothing is staged."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def reduce_scatter_sum(out, inp, group=None):
+    if _staged(group, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(o, inp.cpu(), op=dist.ReduceOp.SUM, group=group)
+        out.copy_(o)
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+
+
+def all_gather_rows(out, inp, group=None):
+    if _staged(group, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu().contiguous(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp.contiguous(), group=group)
+
+
+def all_reduce_sum(t, group=None):
+    if _staged(group, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 class DataParallelEpoch:
     """One epoch across the process group.  Collectives run on torch.distributed's default group
     ('nccl' = RCCL on the GPU box, 'gloo' in the CPU tests)."""
@@ -94,15 +128,15 @@ class DataParallelEpoch:
     def step(self):
         """Returns the global mean loss as a 0-d fp64 tensor (no host sync)."""
         gV, loss_sum = self.b.local_passes()
-        dist.reduce_scatter_tensor(self.g_shard, gV, op=dist.ReduceOp.SUM, group=self.group)
+        reduce_scatter_sum(self.g_shard, gV, self.group)
         V = self.b.V()
         mine = V[self.rank * self.rows_per_rank:(self.rank + 1) * self.rows_per_rank]
         self.b.adam_rows(mine, self.g_shard)
-        dist.all_gather_into_tensor(self.V_gather, mine.contiguous(), group=self.group)
+        all_gather_rows(self.V_gather, mine, self.group)
         V.copy_(self.V_gather)
         self.stats[0] = loss_sum.reshape(())
         self.stats[1] = self.local_count
-        dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce_sum(self.stats, self.group)
         self.b.finish()
         return self.stats[0] / self.stats[1]
 
@@ -160,10 +194,10 @@ def gather_user_embedding(model, n_users, group=None):
     b, e = model.user_block
     sizes = torch.zeros(world, dtype=torch.int64, device=model.user_embedding.device)
     sizes[dist.get_rank(group)] = e - b
-    dist.all_reduce(sizes, group=group)
+    all_reduce_sum(sizes, group)
     mx = int(sizes.max())
     mine = torch.zeros(mx, model.n_components, dtype=torch.float32, device=sizes.device)
     mine[:e - b] = model.user_embedding.float()
     out = torch.empty(world * mx, model.n_components, dtype=torch.float32, device=sizes.device)
-    dist.all_gather_into_tensor(out, mine, group=group)
+    all_gather_rows(out, mine, group)
     return torch.cat([out[g * mx:g * mx + int(sizes[g])] for g in range(world)])[:n_users]

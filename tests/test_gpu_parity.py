@@ -530,6 +530,71 @@ def test_data_parallel_fit_world_size_one_equals_single_process(tm, golden):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('slices', [1, 5])
+def test_midsize_against_c_oracle(tm, monkeypatch, slices):
+    """20K x 5K, r=128, S=512, ~1M power-law interactions: too big for the NumPy oracle's [P, S] temporaries in a
+    test, seconds for the C/OpenMP restatement (oracle/sparse_ref.c).  Whole tables against the step interval, D
+    and delta to 1e-5, for the fused and the sliced user pass."""
+    from oracle import sparse_c as C
+    rng = np.random.default_rng(11)
+    m, n, r, S_, lr = 20000, 5000, 128, 512, 0.1
+    deg = np.clip(np.round(np.exp(3.3 + 0.8 * rng.standard_normal(m))), 1, n // 4).astype(np.int64)
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.minimum((np.power(n + 1.0, rng.random(len(rows))) - 1).astype(np.int64), n - 1)
+    key = np.unique(rows * n + cols)
+    idx = np.stack([key // n, key % n], 1)
+    val = rng.integers(-1, 6, len(idx)).astype(np.float32)      # some zero / negative stored values
+    U0 = (rng.standard_normal((m, r)) / np.sqrt(r)).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) / np.sqrt(r)).astype(np.float32)
+    R = np.argsort(rng.random((m, n)), axis=1)[:, :S_].astype(np.int32)
+    monkeypatch.setenv('TMF_ITEM_SLICES', str(slices))
+    plan = C.Plan(idx, val, m, n, R)
+    Uc, Vc, mean, t = C.wmrb_epoch(U0, V0, plan, n, S_, lr)
+    model = fit_model(tm, U0, V0, idx, val, (m, n), 1, lr, 'wmrb', R, n, S_)
+    assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+    assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
+    assert_step(model.user_embedding.cpu().numpy(), U0, t['gU'], lr, what='wmrb U')
+    assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], lr, what='wmrb V')
+    if slices == 1:
+        Uc, Vc, mean, t = C.mse_epoch(U0, V0, plan, 1e-2)
+        model = fit_model(tm, U0, V0, idx, val, (m, n), 1, 1e-2)
+        assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+        assert_step(model.user_embedding.cpu().numpy(), U0, t['gU'], 1e-2, what='mse U')
+        assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], 1e-2, what='mse V')
+
+
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+def test_two_ranks_on_one_card_match_single_process(tmp_path, loss):
+    """Two ranks, both on cuda:0, gloo group with host-staged collectives (tools/dp_rehearsal.py): the skewed
+    user partition, the padded V, the reduce-scatter -> Adam-on-shard -> all-gather exchange and the loss
+    all-reduce on the HIP engine reproduce the single-process fit.  The item gradient is summed in a different
+    order (two partials), so later epochs are compared at trajectory tolerance, not bitwise."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / 'dp.json'
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tools', 'dp_rehearsal.py'), str(out), loss],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+    res = json.loads(out.read_text())
+    (b0, e0), (b1, e1) = res['blocks']
+    assert b0 == 0 and e0 == b1 and e1 == 3001 and 0 < e0 < 3001
+    assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-9 * abs(res['loss_one'][0])   # same weights, same data
+    assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
+    assert res['U1_equal']                       # after one epoch the user table is bit-identical
+    assert res['V1_frac_close'] > 0.99           # item rows: two partial sums instead of one; |diff| <= 1e-6 except where g ~ 0
+    assert res['V1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
+
+
 @pytest.mark.parametrize('seed', range(12))
 def test_randomized_shapes_against_oracle(tm, monkeypatch, seed):
     """Random small problems: ragged / empty rows, mixed-sign values, every path selector (fused or sliced

@@ -120,3 +120,90 @@ def test_recall_dense_vs_sparse(golden):
         assert np.array_equal(D.recall_at_k_dense(U, V, g['A'], 10), g['recall10'])
         assert np.array_equal(S.recall_at_k_sparse(U, V, g['indices'], g['values'], 10), g['recall10'])
         assert np.array_equal(S.recall_at_k_sparse(U, V, g['indices'], g['values'], 10, True), g['recall10_rows'])
+
+
+# ---- the C / OpenMP restatement (oracle/sparse_ref.c): third independently written oracle + CPU baseline ----
+def _c_oracle():
+    from oracle import sparse_c
+    sparse_c.build()
+    return sparse_c
+
+
+def test_c_oracle_matches_golden_fixtures(golden):
+    """Loss trajectories and first-epoch tables of the dense-oracle fixtures, from the C restatement."""
+    C = _c_oracle()
+    g = golden('c1_mse')
+    m, n = g['A'].shape
+    plan = C.Plan(g['indices'], g['values'], m, n)
+    U, V, losses = g['U0'], g['V0'], []
+    for epoch in range(25):
+        U, V, mean, t = C.mse_epoch(U, V, plan, float(g['lr']))
+        losses.append(mean)
+        if epoch == 0:
+            ref = S.mse_epoch(g['U0'].astype(np.float64), g['V0'].astype(np.float64), g['indices'], g['values'].astype(np.float64),
+                              float(g['lr']))[3]
+            assert_step(U, g['U0'], ref['gU'], float(g['lr']))
+            assert_step(V, g['V0'], ref['gV'], float(g['lr']))
+            assert_step(g['U_1'], g['U0'], ref['gU'], float(g['lr']))   # the fixture itself lies in the same interval
+    assert rel_err(losses, g['loss'][:25]) < 1e-6
+    for name in ('wmrb_small', 'wmrb_mixed'):
+        g = golden(name)
+        m, n = g['A'].shape
+        S_ = int(g['n_samples'])
+        plan = C.Plan(g['indices'], g['values'], m, n, g['R'])
+        U1, V1, mean, t = C.wmrb_epoch(g['U0'], g['V0'], plan, n, S_, float(g['lr']))
+        ref = S.wmrb_epoch(g['U0'].astype(np.float64), g['V0'].astype(np.float64), g['indices'], g['values'].astype(np.float64),
+                           g['R'], n, S_, float(g['lr']))[3]
+        assert abs(mean - float(g['loss'][0])) <= 1e-6 * abs(float(g['loss'][0])), name
+        assert rel_err(t['D'], ref['D']) < 1e-6 and rel_err(t['gU'], ref['gU']) < 1e-6 and rel_err(t['gV'], ref['gV']) < 1e-6
+        if 'D_first' in g:
+            assert rel_err(t['D'], g['D_first']) < 1e-6
+        assert_step(U1, g['U0'], ref['gU'], float(g['lr']))
+        assert_step(V1, g['V0'], ref['gV'], float(g['lr']))
+        U2, V2, mean2, _ = C.wmrb_epoch(U1, V1, plan, n, S_, float(g['lr']))
+        assert abs(mean2 - float(g['loss'][1])) <= 1e-5 * abs(float(g['loss'][1])), name
+
+
+def test_c_oracle_random_shapes_and_thread_counts():
+    """Ragged / empty rows, shuffled input order, non-positive values; the result does not depend on the
+    number of OpenMP threads (every row is reduced by one thread in a fixed order)."""
+    C = _c_oracle()
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        m, n, r = int(rng.integers(1, 70)), int(rng.integers(2, 60)), int(rng.choice([1, 3, 8, 17, 64]))
+        S_ = int(rng.integers(1, n + 1))
+        A = (rng.random((m, n)) < rng.choice([0.0, 0.05, 0.4])) * rng.integers(-2, 6, (m, n))
+        idx, val = np.argwhere(A != 0), A[A != 0].astype(np.float32)
+        p = rng.permutation(len(val))
+        idx, val = idx[p], val[p]
+        U = (rng.standard_normal((m, r)) * 0.4).astype(np.float32)
+        V = (rng.standard_normal((n, r)) * 0.4).astype(np.float32)
+        R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
+        plan = C.Plan(idx, val, m, n, R)
+        outs = []
+        for nt in (1, 3):
+            C.set_threads(nt)
+            outs.append((C.mse_epoch(U, V, plan, 0.01), C.wmrb_epoch(U, V, plan, n, S_, 0.1)))
+        C.set_threads(os.cpu_count() or 1)
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            assert np.array_equal(a[3]['delta'], b[3]['delta'])
+        (mU, mV, mmean, mt), (wU, wV, wmean, wt) = outs[0]
+        U64, V64, v64 = U.astype(np.float64), V.astype(np.float64), val.astype(np.float64)
+        if len(val):
+            ref = S.mse_epoch(U64, V64, idx, v64, 0.01)
+            assert abs(mmean - ref[2]) <= 1e-6 * abs(ref[2])
+            assert rel_err(mt['delta'], ref[3]['delta']) < 1e-6
+            assert_step(mU, U, ref[3]['gU'], 0.01)
+            assert_step(mV, V, ref[3]['gV'], 0.01)
+        else:
+            assert np.array_equal(mU, U) and np.array_equal(mV, V)
+        ref = S.wmrb_epoch(U64, V64, idx, v64, R, n, S_, 0.1)
+        if (val > 0).any():
+            assert abs(wmean - ref[2]) <= 1e-6 * abs(ref[2])
+            assert wt['n_pos'] == int((val > 0).sum())
+            assert rel_err(wt['D'], ref[3]['D']) < 1e-5
+            assert_step(wU, U, ref[3]['gU'], 0.1)
+            assert_step(wV, V, ref[3]['gV'], 0.1)
+        else:
+            assert np.array_equal(wU, U) and np.array_equal(wV, V)

@@ -1,0 +1,78 @@
+"""Rank of a multi-rank rehearsal of the data-parallel fit on ONE card: every rank uses cuda:0 and a gloo
+group (RCCL refuses duplicate devices), so dist.py stages the collectives through the host while the local
+passes run on the HIP engine - the same code path bench.py --gpus N takes, minus the wire.
+Rank 0 also runs the single-process fit and writes the comparison as JSON.
+
+env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT;  usage: python tools/dp_rehearsal.py OUT.json [loss]"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from teamoflow.mf.initializer_graphs import FixedInitializer  # noqa: E402
+from teamoflow.mf.loss_graphs import MSELoss, WMRBLoss  # noqa: E402
+from teamoflow.mf.matrix_factorization import MatrixFactorization  # noqa: E402
+from teamoflow.mf.sparse import SparseInteractions, eye  # noqa: E402
+from teamoflow_amd import dist as tdist  # noqa: E402
+
+
+def main():
+    out, loss = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'wmrb')
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    m, n, r, S, lr, epochs = 3001, 701, 64, 48, 0.05, 3      # n not a multiple of world: V is padded
+    deg = np.minimum(rng.zipf(1.6, m), n // 2)                 # skewed users: the partition is by cost, not by count
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+    order = np.lexsort((cols, rows))
+    idx = np.stack([rows, cols], 1)[order]
+    val = rng.integers(1, 6, len(idx)).astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, S, replace=False) for _ in range(m)])
+
+    def run(parallel, epochs=epochs):
+        kw = dict(user_weight_graph=FixedInitializer(U0), item_weight_graph=FixedInitializer(V0))
+        if loss == 'wmrb':
+            kw.update(loss_graph=WMRBLoss(), n_users=m, n_items=n, n_samples=S)
+        else:
+            kw.update(loss_graph=MSELoss())
+        model = MatrixFactorization(r, **kw)
+        model.verbose, model.data_parallel = False, parallel
+        if loss == 'wmrb':
+            model.random_ind = torch.as_tensor(R)
+        model.fit(epochs, eye(m), eye(n), SparseInteractions(idx, val, (m, n)), lr=lr)
+        return model
+
+    dp1 = run(True, 1)                                         # one epoch: U must not depend on the partition at all
+    U_dp1 = tdist.gather_user_embedding(dp1, m)
+    dp = run(True)
+    U_dp = tdist.gather_user_embedding(dp, m)
+    blocks = [None] * world
+    dist.all_gather_object(blocks, dp.user_block)
+    if rank == 0:
+        one, one1 = run(False), run(False, 1)
+        res = {'U1_equal': bool(torch.equal(U_dp1, one1.user_embedding)),
+               'V1_frac_close': float(((dp1.item_embedding - one1.item_embedding).abs() <= 1e-6).float().mean()),
+               'V1_max_abs_diff': float((dp1.item_embedding - one1.item_embedding).abs().max()),
+               'world': world, 'loss': loss, 'blocks': blocks,
+               'loss_dp': dp.loss_history_, 'loss_one': one.loss_history_,
+               'U_max_abs_diff': float((U_dp - one.user_embedding).abs().max()),
+               'V_max_abs_diff': float((dp.item_embedding - one.item_embedding).abs().max()),
+               'U_frac_equal': float((U_dp == one.user_embedding).float().mean()),
+               'V_frac_equal': float((dp.item_embedding == one.item_embedding).float().mean()),
+               'recall_dp_local': float(dp.recall_at_k(SparseInteractions(idx, val, (m, n))).mean())
+               if world == 1 else None}
+        with open(out, 'w') as f:
+            json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
