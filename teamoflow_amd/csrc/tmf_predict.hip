@@ -300,8 +300,10 @@ extern "C" int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, floa
 namespace tmf {
 
 constexpr int FBM = 128, FBN = 128, FBK = 32, FLD = FBN + 1, FCAP = 16, FMAXK = 32;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NCH>  // K_PAD = 32 * NCH
+// MODE 2: K % 4 == 0 and V < 4 GB (buffer loads, constant per-thread offsets), 1: K % 4 == 0 (branch-free), 0: any K
+template <int NCH, int MODE>  // K_PAD = 32 * NCH
 __global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict__ A, const float* __restrict__ B,
                                                          int64_t m, int64_t n, int K, int64_t lda, int64_t ldb, int k,
                                                          int clamp, int32_t* __restrict__ out_idx,
@@ -347,43 +349,110 @@ __global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict
     const int s_item = tid >> 3, s_k4 = tid & 7;
     const int64_t ntiles = (n + FBN - 1) / FBN;
     const int64_t nchunks = ntiles * NCH;
-    float4 stage[4];
-    auto g_load = [&](int64_t g) {
-        const int64_t tile = g / NCH;
-        const int c = (int)(g % NCH);
-        const int kk = 32 * c + 4 * s_k4;
+    constexpr bool ALIGNED = MODE >= 1;
+    uint32_t voff[4];  // MODE 2: byte offset of this thread's four 16-byte pieces inside a (tile, k-chunk) block of V
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(B), 0, MODE == 2 ? (int)(uint32_t)(n * ldb * 4) : 0, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t item = tile * FBN + s_item + 32 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < nchunks && item < n) {
-                const float* p = B + item * ldb + kk;
-                if (kk + 3 < K) v = *reinterpret_cast<const float4*>(p);
-                else { if (kk < K) v.x = p[0]; if (kk + 1 < K) v.y = p[1]; if (kk + 2 < K) v.z = p[2]; }
+    for (int q = 0; q < 4; ++q) voff[q] = (uint32_t)(((int64_t)(s_item + 32 * q) * ldb + 4 * s_k4) * 4);
+    float4 stg[2][4];  // two staging register sets, alternating by chunk parity (see the prologue below)
+    auto g_load = [&](int64_t g, float4* stage) {
+        if constexpr (MODE == 2) {
+            // V is read through a buffer descriptor: every thread keeps the same four 32-bit byte offsets for the whole
+            // kernel and adds the wave-uniform offset of the (tile, k-chunk) block - a chunk costs a few scalar
+            // instructions, four v_add_u32 and four loads.  The hardware range check returns zeros for rows >= n (the
+            // ragged last tile and the two prefetches past the end); k-slots >= K are zeroed at the LDS write.
+            const uint32_t block_off = (uint32_t)(((g / NCH) * FBN * ldb + 32 * (g % NCH)) * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, (int)(voff[q] + block_off), 0, 0);
+                stage[q] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
+                                       __uint_as_float(raw[3]));
             }
-            stage[q] = v;
+        } else if constexpr (MODE == 1) {
+            // Branch-free: chunk and item indices are clamped into range (columns >= n are ignored by offer(), the two
+            // prefetches past the last chunk re-read it) and a k-slot past K is zeroed by a select, so a chunk costs
+            // four address computations and four 16-byte loads - no exec-mask juggling next to the MFMAs (the select runs when
+            // the registers are written to LDS, not here: touching a load's target waits for the load).
+            const int64_t gg = g < nchunks ? g : nchunks - 1;
+            const int64_t tile = gg / NCH;
+            const int c = (int)(gg % NCH);
+            const int kk = 32 * c + 4 * s_k4;
+            const int kc = kk + 4 <= K ? kk : K - 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int64_t item = tile * FBN + s_item + 32 * q;
+                item = item < n ? item : n - 1;
+                stage[q] = *reinterpret_cast<const float4*>(B + item * ldb + kc);  // zeroed in s_write_from if kk >= K
+            }
+        } else {
+            const int64_t tile = g / NCH;
+            const int c = (int)(g % NCH);
+            const int kk = 32 * c + 4 * s_k4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t item = tile * FBN + s_item + 32 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < nchunks && item < n) {
+                    const float* p = B + item * ldb + kk;
+                    if (kk + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                    else { if (kk < K) v.x = p[0]; if (kk + 1 < K) v.y = p[1]; if (kk + 2 < K) v.z = p[2]; }
+                }
+                stage[q] = v;
+            }
         }
     };
-    auto s_write = [&](int slot) {
+    auto s_write_from = [&](int slot, const float4* src, int c) {  // c = k-chunk of the data in `src`
         float* dst = Bs + slot * FBK * FLD;
+        const bool live = !ALIGNED || (32 * c + 4 * s_k4 < K);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int item = s_item + 32 * q;
-            dst[(4 * s_k4 + 0) * FLD + item] = stage[q].x;
-            dst[(4 * s_k4 + 1) * FLD + item] = stage[q].y;
-            dst[(4 * s_k4 + 2) * FLD + item] = stage[q].z;
-            dst[(4 * s_k4 + 3) * FLD + item] = stage[q].w;
+            dst[(4 * s_k4 + 0) * FLD + item] = live ? src[q].x : 0.f;
+            dst[(4 * s_k4 + 1) * FLD + item] = live ? src[q].y : 0.f;
+            dst[(4 * s_k4 + 2) * FLD + item] = live ? src[q].z : 0.f;
+            dst[(4 * s_k4 + 3) * FLD + item] = live ? src[q].w : 0.f;
         }
     };
-    g_load(0); s_write(0);
-    g_load(1); s_write(1);
+    // Global loads run THREE chunks ahead of the MFMAs that consume them: chunk g + 3 is requested at the top of chunk
+    // g into one register set, while the other set (requested a chunk earlier, for chunk g + 2) is written to LDS at
+    // the end of chunk g - two chunks (>= 3 us) of latency budget instead of one, which the L2-miss / Infinity-Cache
+    // latency under load overran (measured: 17 % of the kernel).  The sets swap roles every chunk; with an even NCH
+    // the role is the compile-time parity of the chunk index inside the tile, so no register is ever copied (a copy
+    // of an in-flight load target would wait for it).  NCH = 1 (r <= 32, far from MFMA-bound) copies instead.
+    g_load(0, stg[0]); s_write_from(0, stg[0], 0);
+    g_load(1, stg[0]); s_write_from(1, stg[0], 1 % NCH);
+    g_load(2, stg[1]);
     __syncthreads();
 
     f32x16 acc[4];  // the wave's 32 users x the tile's 4 x 32 items
-    auto offer = [&](int64_t col0, int group) {
-        // group < 0: every column; otherwise only local columns [16 group, 16 group + 16)
+    // Thresholds of the 16 rows this lane holds accumulator elements of, kept in registers: tau only changes in
+    // merge_wave(), after which they are re-read.  The steady state of a tile is then 16 x (max of the row's four
+    // values, one compare) and ONE wave-uniform branch - the per-element tests, LDS traffic and atomics below run
+    // only for the rows whose maximum beats their threshold (10/t of them at tile t for k = 10).
+    float tq[16];
+    auto load_tau = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
+    };
+    load_tau();
+    auto prefilter = [&]() -> unsigned {
+        unsigned pass = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+            float mx = fmaxf(fmaxf(acc[0][q], acc[1][q]), fmaxf(acc[2][q], acc[3][q]));
+            if (clamp) mx = fmaxf(mx, 0.f);
+            pass |= (mx > tq[q]) ? (1u << q) : 0u;
+        }
+        return pass;
+    };
+    auto offer = [&](int64_t col0, int group, unsigned pass) {
+        // group < 0: every column; otherwise only local columns [16 group, 16 group + 16)
+        // (a ballot + popcount slot assignment instead of the LDS atomic was measured slower: it makes all 64 lanes walk
+        // every row that has a candidate anywhere in the wave)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (!((pass >> q) & 1u)) continue;
             const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
             const float t = tau[row];
 #pragma unroll
@@ -423,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict
     };
 
     int64_t g = 0;
+    int c_prev = 0;  // lanes h == 0: pending entries of the lane's row that predate the current tile
     for (int64_t tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -430,35 +500,67 @@ __global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c, ++g) {
-            g_load(g + 2);
-            const float* bs = Bs + (int)(g % 3) * FBK * FLD;
+            g_load(g + 3, stg[c & 1]);
+            const float* bs = Bs + (int)(g % 3) * FBK * FLD + h * FLD + l31;
+            // B operands one k-step ahead of the MFMAs that consume them (two register sets): the LDS latency of
+            // step ks + 1 hides behind the four MFMAs of step ks instead of stalling every second MFMA
+            float bq[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[0][j] = bs[32 * j];
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                const int kl = 2 * ks + h;
+                if (ks + 1 < 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bq[(ks + 1) & 1][j] = bs[2 * (ks + 1) * FLD + 32 * j];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads of step ks + 1 ahead of the MFMAs of step ks
                 const float av = a[16 * c + ks];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bs[kl * FLD + 32 * j + l31], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[ks & 1][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            s_write((int)((g + 2) % 3));
+            s_write_from((int)((g + 2) % 3), stg[(c & 1) ^ 1], (c + 2) % NCH);
+            if constexpr (NCH == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) stg[1][q] = stg[0][q];
+            }
             __syncthreads();
         }
         // top-k update: the 32 rows of a wave are touched by that wave only (pending lists, thresholds, sorted
         // lists), so this part needs no workgroup barrier - LDS operations of one wave complete in order.
         const int64_t col0 = tile * FBN;
-        offer(col0, -1);
-        const int my_row = 32 * wave + l31;
-        const bool over = __any((h == 0) && cnt[my_row] > FCAP);  // wave-uniform
-        if (over) {  // re-offer the tile in 8 groups of 16 columns
-            if (h == 0) cnt[my_row] = 0;
-            for (int grp = 0; grp < FBN / 16; ++grp) {
-                offer(col0, grp);
+        const unsigned pass = prefilter();
+        if (__any(pass != 0u)) {  // wave-uniform
+            // Candidates are only APPENDED to the row's pending buffer here; the sorted lists (and with them the
+            // thresholds) are brought up to date when some row of the wave has filled half of its buffer.  A stale
+            // threshold is a lower bound of the true one, so nothing is lost - a few more candidates are appended and
+            // rejected by the merge - while the serial, LDS-latency-bound insertion runs ~20 times per row block
+            // instead of on most tiles.
+            offer(col0, -1, pass);
+            const int my_row = 32 * wave + l31;
+            const int c_now = (h == 0) ? cnt[my_row] : 0;
+            if (__any(c_now > FCAP)) {
+                // overflow: drop this tile's partial appends (keep the older ones), merge, then re-offer the tile in
+                // 8 groups of 16 columns with a merge after each (thresholds only rise: `pass` stays a superset)
+                if (h == 0) cnt[my_row] = c_prev;
                 merge_wave();
+                for (int grp = 0; grp < FBN / 16; ++grp) {
+                    offer(col0, grp, pass);
+                    merge_wave();
+                }
+                c_prev = 0;
+                load_tau();
+            } else if (__any(c_now > FCAP / 2)) {
+                merge_wave();
+                c_prev = 0;
+                load_tau();
+            } else {
+                c_prev = c_now;
             }
-        } else {
-            merge_wave();
         }
     }
+    merge_wave();  // whatever is still pending
     __syncthreads();
     if (tid < FBM && row0 + tid < m) {
         for (int j = 0; j < k; ++j) {
@@ -468,22 +570,31 @@ __global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict
     }
 }
 
-template <int NCH>
-static int launch_predict_topk(const float* A, const float* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
+template <int NCH, int MODE>
+static int launch_predict_topk_impl(const float* A, const float* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
                                int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
     const size_t lds = sizeof(float) * (3 * FBK * FLD + FBM) + sizeof(int) * (FBM + 4) + 8 * (size_t)FCAP * FBM +
                        8 * (size_t)k * FBM;
     static size_t allowed = 64 * 1024;
     if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk<NCH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk<NCH, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return TMF_E_LAUNCH; }
         allowed = lds;
     }
     const int64_t blocks = (m + FBM - 1) / FBM;
-    hipLaunchKernelGGL((k_predict_topk<NCH>), dim3((unsigned)blocks), dim3(256), lds, stream, A, B, m, n, K, lda, ldb, k,
+    hipLaunchKernelGGL((k_predict_topk<NCH, MODE>), dim3((unsigned)blocks), dim3(256), lds, stream, A, B, m, n, K, lda, ldb, k,
                        clamp, out_idx, out_val);
     return check_launch("tmf_predict_topk_f32");
+}
+
+template <int NCH>
+static int launch_predict_topk(const float* A, const float* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
+                               int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
+    if (K % 4 == 0 && (n + 4 * FBN) * ldb * 4 < ((int64_t)1 << 32))  // 32-bit byte offsets into V
+        return launch_predict_topk_impl<NCH, 2>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
+    if (K % 4 == 0) return launch_predict_topk_impl<NCH, 1>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
+    return launch_predict_topk_impl<NCH, 0>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
 }
 
 }  // namespace tmf
@@ -518,9 +629,10 @@ extern "C" int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, i
 namespace tmf {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-constexpr int HBM_ = 256, HBN = 128, HBK = 64, HROW = 144 /* bytes */, HCAP = 8, HMAXK = 32;
+constexpr int HBM_ = 256, HBN = 128, HBK = 64, HROW = 144 /* bytes */, HCAP = 16, HMAXK = 32;
 
-template <int NCH>  // K_PAD = 64 * NCH
+// MODE 2: K % 8 == 0 and V < 4 GB (buffer loads with constant per-thread offsets, 3 chunks of read-ahead); 0: any K
+template <int NCH, int MODE>  // K_PAD = 64 * NCH
 __global__ __launch_bounds__(512, 2) void k_predict_topk_bf16(const __bf16* __restrict__ A, const __bf16* __restrict__ B,
                                                               int64_t m, int64_t n, int K, int64_t lda, int64_t ldb, int k,
                                                               int clamp, int32_t* __restrict__ out_idx,
@@ -567,40 +679,77 @@ __global__ __launch_bounds__(512, 2) void k_predict_topk_bf16(const __bf16* __re
     const int s_item = tid >> 3, s_slot = tid & 7;
     const int64_t ntiles = (n + HBN - 1) / HBN;
     const int64_t nchunks = ntiles * NCH;
-    bf16x8_t stage[2];
-    auto g_load = [&](int64_t g) {
-        const int64_t tile = g / NCH;
-        const int c = (int)(g % NCH);
-        const int kk = 64 * c + 8 * s_slot;
+    uint32_t voff[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int64_t item = tile * HBN + s_item + 64 * q;
-            bf16x8_t v;
+    for (int q = 0; q < 2; ++q) voff[q] = (uint32_t)(((int64_t)(s_item + 64 * q) * ldb + 8 * s_slot) * 2);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(B), 0, MODE == 2 ? (int)(uint32_t)(n * ldb * 2) : 0, 0x00020000);
+    bf16x8_t stg[2][2];  // two staging register sets, alternating by chunk parity (as in k_predict_topk)
+    auto g_load = [&](int64_t g, bf16x8_t* stage) {
+        if constexpr (MODE == 2) {
+            // rows >= n come back as zeros from the buffer range check; k-slots >= K are zeroed at the LDS write
+            const uint32_t block_off = (uint32_t)(((g / NCH) * HBN * ldb + 64 * (g % NCH)) * 2);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
-            if (g < nchunks && item < n && kk < K) {
-                const __bf16* p = B + item * ldb + kk;
-                if (kk + 7 < K) v = *reinterpret_cast<const bf16x8_t*>(p);
-                else
-                    for (int e = 0; e < 8; ++e) if (kk + e < K) v[e] = p[e];
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, (int)(voff[q] + block_off), 0, 0);
+                stage[q] = __builtin_bit_cast(bf16x8_t, raw);
             }
-            stage[q] = v;
+        } else {
+            const int64_t tile = g / NCH;
+            const int c = (int)(g % NCH);
+            const int kk = 64 * c + 8 * s_slot;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int64_t item = tile * HBN + s_item + 64 * q;
+                bf16x8_t v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+                if (g < nchunks && item < n && kk < K) {
+                    const __bf16* p = B + item * ldb + kk;
+                    if (kk + 7 < K) v = *reinterpret_cast<const bf16x8_t*>(p);
+                    else
+                        for (int e = 0; e < 8; ++e) if (kk + e < K) v[e] = p[e];
+                }
+                stage[q] = v;
+            }
         }
     };
-    auto s_write = [&](int slot) {
+    auto s_write_from = [&](int slot, const bf16x8_t* src, int c) {  // c = k-chunk of the data in `src`
         char* dst = Bs + slot * HBN * HROW;
+        const bool live = MODE != 2 || (64 * c + 8 * s_slot < K);
+        bf16x8_t zero;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            *reinterpret_cast<bf16x8_t*>(dst + (s_item + 64 * q) * HROW + s_slot * 16) = stage[q];
+            *reinterpret_cast<bf16x8_t*>(dst + (s_item + 64 * q) * HROW + s_slot * 16) = live ? src[q] : zero;
     };
-    g_load(0); s_write(0);
-    g_load(1); s_write(1);
+    g_load(0, stg[0]); s_write_from(0, stg[0], 0);
+    g_load(1, stg[0]); s_write_from(1, stg[0], 1 % NCH);
+    g_load(2, stg[1]);
     __syncthreads();
 
     f32x16 acc[4];
-    auto offer = [&](int64_t col0, int group) {
+    float tq[16];  // register copy of this lane's 16 row thresholds (see k_predict_topk)
+    auto load_tau = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
+    };
+    load_tau();
+    auto prefilter = [&]() -> unsigned {
+        unsigned pass = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+            float mx = fmaxf(fmaxf(acc[0][q], acc[1][q]), fmaxf(acc[2][q], acc[3][q]));
+            if (clamp) mx = fmaxf(mx, 0.f);
+            pass |= (mx > tq[q]) ? (1u << q) : 0u;
+        }
+        return pass;
+    };
+    auto offer = [&](int64_t col0, int group, unsigned pass) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (!((pass >> q) & 1u)) continue;
             const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
             const float t = tau[row];
 #pragma unroll
@@ -640,6 +789,7 @@ __global__ __launch_bounds__(512, 2) void k_predict_topk_bf16(const __bf16* __re
     };
 
     int64_t g = 0;
+    int c_prev = 0;
     for (int64_t tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -647,33 +797,56 @@ __global__ __launch_bounds__(512, 2) void k_predict_topk_bf16(const __bf16* __re
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c, ++g) {
-            g_load(g + 2);
-            const char* bs = Bs + (int)(g % 3) * HBN * HROW;
+            g_load(g + 3, stg[c & 1]);
+            const char* bs = Bs + (int)(g % 3) * HBN * HROW + l31 * HROW + h * 16;
+            bf16x8_t bq[2][4];  // B operands one k-step ahead of their MFMAs (see k_predict_topk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[0][j] = *reinterpret_cast<const bf16x8_t*>(bs + 32 * j * HROW);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(bs + (32 * j + l31) * HROW + ks * 32 + h * 16);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 * c + ks], b, acc[j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        bq[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8_t*>(bs + 32 * j * HROW + (ks + 1) * 32);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 * c + ks], bq[ks & 1][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            s_write((int)((g + 2) % 3));
+            s_write_from((int)((g + 2) % 3), stg[(c & 1) ^ 1], (c + 2) % NCH);
+            if constexpr (NCH == 1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) stg[1][q] = stg[0][q];
+            }
             __syncthreads();
         }
         const int64_t col0 = tile * HBN;
-        offer(col0, -1);
-        const int my_row = 32 * wave + l31;
-        const bool over = __any((h == 0) && cnt[my_row] > HCAP);
-        if (over) {  // re-offer the tile in 16 groups of 8 columns
-            if (h == 0) cnt[my_row] = 0;
-            for (int grp = 0; grp < HBN / 8; ++grp) {
-                offer(col0, grp);
+        const unsigned pass = prefilter();
+        if (__any(pass != 0u)) {  // candidates are appended; lists and thresholds catch up when a buffer is half full
+            offer(col0, -1, pass);
+            const int my_row = 32 * wave + l31;
+            const int c_now = (h == 0) ? cnt[my_row] : 0;
+            if (__any(c_now > HCAP)) {  // overflow: keep the older appends, re-offer this tile in 16 groups of 8 columns
+                if (h == 0) cnt[my_row] = c_prev;
                 merge_wave();
+                for (int grp = 0; grp < HBN / 8; ++grp) {
+                    offer(col0, grp, pass);
+                    merge_wave();
+                }
+                c_prev = 0;
+                load_tau();
+            } else if (__any(c_now > HCAP / 2)) {
+                merge_wave();
+                c_prev = 0;
+                load_tau();
+            } else {
+                c_prev = c_now;
             }
-        } else {
-            merge_wave();
         }
     }
+    merge_wave();  // whatever is still pending
     __syncthreads();
     if (tid < HBM_ && row0 + tid < m) {
         for (int j = 0; j < k; ++j) {
@@ -683,22 +856,30 @@ __global__ __launch_bounds__(512, 2) void k_predict_topk_bf16(const __bf16* __re
     }
 }
 
-template <int NCH>
-static int launch_predict_topk_bf16(const void* A, const void* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
+template <int NCH, int MODE>
+static int launch_predict_topk_bf16_impl(const void* A, const void* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
                                     int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
     const size_t lds = (size_t)3 * HBN * HROW + sizeof(float) * HBM_ + sizeof(int) * HBM_ + 8 * (size_t)HCAP * HBM_ +
                        8 * (size_t)k * HBM_;
     static size_t allowed = 64 * 1024;
     if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk_bf16<NCH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk_bf16<NCH, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return TMF_E_LAUNCH; }
         allowed = lds;
     }
     const int64_t blocks = (m + HBM_ - 1) / HBM_;
-    hipLaunchKernelGGL((k_predict_topk_bf16<NCH>), dim3((unsigned)blocks), dim3(512), lds, stream, (const __bf16*)A,
+    hipLaunchKernelGGL((k_predict_topk_bf16<NCH, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, (const __bf16*)A,
                        (const __bf16*)B, m, n, K, lda, ldb, k, clamp, out_idx, out_val);
     return check_launch("tmf_predict_topk_bf16");
+}
+
+template <int NCH>
+static int launch_predict_topk_bf16(const void* A, const void* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
+                                    int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
+    if (K % 8 == 0 && (n + 4 * HBN) * ldb * 2 < ((int64_t)1 << 32))
+        return launch_predict_topk_bf16_impl<NCH, 2>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
+    return launch_predict_topk_bf16_impl<NCH, 0>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
 }
 
 }  // namespace tmf

@@ -390,6 +390,30 @@ def test_fused_predict_topk_bf16(tm):
     assert np.array_equal(model.retrieve_user_recs(k=10), idx.cpu().numpy())
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_fused_predict_topk_deferred_merges(tm, dtype):
+    """Rows whose running top-k is beaten every 20..41 items: a few candidates per 128-item tile, so the pending
+    buffers fill over several tiles, rows of one wave reach the merge threshold at different times, and the final
+    flush matters (the last records sit in the last tiles).  Ragged last tile; exact expected ranking."""
+    from oracle import sparse_ref as S
+    n, r, m = 3001, 8, 300
+    period = 20 + 3 * np.arange(r)
+    j = np.arange(n)
+    V = np.where(j[:, None] % period[None, :] == 0, (j // 16 + 1)[:, None], -1).astype(np.float32)
+    U = np.eye(r, dtype=np.float32)[np.arange(m) % r]
+    U[7] = 0                                            # a row of all-equal (zero) scores: lowest indices win
+    sc = U @ V.T
+    Ut, Vt = torch.tensor(U), torch.tensor(V)
+    if dtype == 'bf16':
+        Ut, Vt = Ut.to(torch.bfloat16).cuda(), Vt.to(torch.bfloat16).cuda()
+    for k in (1, 10, 32):
+        for clamp in (False, True):
+            ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
+            vals, got = tm.ops.predict_topk(Ut, Vt, k, clamp_negatives=clamp, return_values=True)
+            assert np.array_equal(got.cpu().numpy(), ref), (dtype, k, clamp)
+            assert np.array_equal(vals.cpu().numpy(), np.take_along_axis(np.where(sc > 0, sc, 0) if clamp else sc, ref, 1))
+
+
 def test_predict_gemm_shapes(tm):
     rng = np.random.default_rng(3)
     for m, n, r in [(1, 1, 1), (100, 50, 5), (129, 257, 32), (300, 1000, 128), (64, 64, 7)]:
