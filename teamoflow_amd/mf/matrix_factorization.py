@@ -406,11 +406,54 @@ class MatrixFactorization:
                      'Number of Users': 'n_users', 'Number of Items': 'n_items', 'Number of Samples': 'n_samples',
                      'Generate Sample': 'generate_sample'}
 
+    def save(self, path, include_samples=True):
+        """Extension: save_model()'s two dicts plus the tables in ONE file (torch.save).  The
+        plug-in objects are pickled as they are; ``include_samples=False`` leaves the [m, S] negative table out."""
+        _save_to_disk(self, path, include_samples)
+
+    @classmethod
+    def load(cls, path, device=None):
+        """Inverse of ``save``: a model ready for predict / recall_at_k / a further fit."""
+        return _load_from_disk(cls, path, device)
+
     @classmethod
     def from_saved(cls, config):
         """:465-475: ``cls(**config)``.  Also accepts save_model()'s display-key dict (in the
         reference that raises TypeError - SURVEY.md §5)."""
         return cls(**{cls._DISPLAY_KEYS.get(k, k): v for k, v in config.items()})
+
+
+def _save_to_disk(model, path, include_samples=True):
+    config, results = model.save_model()
+    blob = {'format': 'teamoflow_amd.mf/1', 'config': config,
+            'user_embedding': None if model.user_embedding is None else model.user_embedding.detach().float().cpu(),
+            'item_embedding': None if model.item_embedding is None else model.item_embedding.detach().float().cpu(),
+            'factor_dtype': str(model.factor_dtype).replace('torch.', ''),
+            'loss_history': list(getattr(model, 'loss_history_', []) or []),
+            'random_ind': (torch.as_tensor(model.random_ind).cpu() if include_samples and model.random_ind is not None else None)}
+    torch.save(blob, path)
+
+
+def _load_from_disk(cls, path, device=None):
+    blob = torch.load(path, map_location='cpu', weights_only=False)
+    if blob.get('format') != 'teamoflow_amd.mf/1':
+        raise ValueError(f'{path}: not a teamoflow_amd model file')
+    cfg = dict(blob['config'])
+    cfg['Generate Sample'] = False          # the table comes from the file (or is absent), never redrawn
+    model = cls.from_saved(cfg)
+    model.generate_sample = blob['config']['Generate Sample']
+    dev = default_device() if device is None else torch.device(device)
+    dt = getattr(torch, blob['factor_dtype'])
+    model.factor_dtype = dt
+    for name in ('user_embedding', 'item_embedding'):
+        t = blob[name]
+        setattr(model, name, None if t is None else t.to(device=dev, dtype=dt))
+    model.user_trainable = [model.user_embedding] if model.user_embedding is not None else None
+    model.item_trainable = [model.item_embedding] if model.item_embedding is not None else None
+    model.loss_history_ = blob['loss_history']
+    if blob['random_ind'] is not None:
+        model.random_ind = blob['random_ind'].to(dev)
+    return model
 
 
 def _adam_scalars(lr):

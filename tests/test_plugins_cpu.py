@@ -103,3 +103,28 @@ def test_initializers_normalise_globally():
         assert abs(float((w.detach() ** 2).sum()) - 1.0) < 1e-5  # whole-matrix L2 norm 1 (initializer_graphs.py:34,51)
     with pytest.raises(ValueError):
         FixedInitializer(np.zeros((3, 2))).initialize_weights(4, 2)
+
+
+def test_save_and_load_roundtrip(tmp_path):
+    """Extension: one-file persistence.  Tables, plug-in objects, the negative table and the loss history survive."""
+    import numpy as np
+    import torch
+    from teamoflow.mf.initializer_graphs import UniformInitializer
+    from teamoflow.mf.loss_graphs import WMRBLoss
+    from teamoflow.mf.matrix_factorization import MatrixFactorization
+    np.random.seed(3)
+    model = MatrixFactorization(4, loss_graph=WMRBLoss(), user_weight_graph=UniformInitializer(), n_users=6, n_items=9,
+                                n_samples=5, generate_sample=True)
+    model.user_embedding = torch.arange(24, dtype=torch.float32).reshape(6, 4)
+    model.item_embedding = torch.arange(36, dtype=torch.float32).reshape(9, 4) / 7
+    model.loss_history_ = [3.0, 2.5]
+    path = tmp_path / 'model.pt'
+    model.save(path)
+    back = MatrixFactorization.load(path, device='cpu')
+    assert isinstance(back.loss_graph, WMRBLoss) and isinstance(back.user_weight_graph, UniformInitializer)
+    assert (back.n_components, back.n_users, back.n_items, back.n_samples, back.generate_sample) == (4, 6, 9, 5, True)
+    assert torch.equal(back.user_embedding, model.user_embedding) and torch.equal(back.item_embedding, model.item_embedding)
+    assert torch.equal(torch.as_tensor(back.random_ind).cpu(), torch.as_tensor(model.random_ind).cpu())
+    assert back.loss_history_ == [3.0, 2.5]
+    model.save(path, include_samples=False)
+    assert MatrixFactorization.load(path, device='cpu').random_ind is None
