@@ -276,7 +276,7 @@ def main():
     if args.loss == 'wmrb':
         R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
         wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r), n_items=n),
-                                 item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)))
+                                 item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)), n_components=r)
     tdtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     sbytes = 2 if args.dtype == 'bf16' else 4
     st = _engine.TrainState(U0, V0, plan, r, wplan, dtype=tdtype)

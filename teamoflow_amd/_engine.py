@@ -198,10 +198,14 @@ class WmrbPlan:
     item, blocks outermost): the waves running at any moment then gather U rows of ONE block of users,
     which fits the Infinity Cache, instead of rows scattered over the whole table."""
 
-    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1):
+    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128):
         dev = R.device
         m, S = R.shape
         self.n_slices = max(1, int(item_slices))
+        if self.n_slices > 1 and _lib.load_library().tmf_wmrb_user_workspace_bytes(1, S, max(int(n_components), 512)) > 0:  # conservative ld
+            # scores + D of one user do not fit LDS (n_samples beyond ~13K): only the fused pass has the
+            # global-workspace variant, so the catalog is not sliced however large it is
+            self.n_slices = 1
         self.sample_perm = None
         if self.n_slices > 1:
             # every user's negatives in ascending item order (the order of s is immaterial to the loss);

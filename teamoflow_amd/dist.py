@@ -163,14 +163,14 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
     idx[:, 0] -= b
     val = interactions.values[keep]
     n_pad = padded_rows(n_items, world)
-    plan = _engine.InteractionPlan(idx, val, e - b, n_pad, csc=not wmrb)
+    plan = _engine.InteractionPlan(idx, val, e - b, n_pad, user_chunks=1 if wmrb else _engine.mse_user_chunks(), csc=not wmrb)
     ld = _lib.padded_ld(model.n_components, model.factor_dtype)
     wplan, c = None, 0.0
     if wmrb:
         R = torch.as_tensor(model.random_ind)[b:e].to(device=dev, dtype=torch.int32).contiguous()
         c = model.n_items / model.n_samples
         wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(e - b, ld, n_items=n_pad),
-                                 item_slices=_engine.default_item_slices(n_pad, ld))
+                                 item_slices=_engine.default_item_slices(n_pad, ld), n_components=model.n_components)
     V0p = torch.zeros(n_pad, model.n_components, dtype=torch.float32, device=dev)
     V0p[:n_items] = torch.as_tensor(V0).detach().to(device=dev, dtype=torch.float32)
     st = _engine.TrainState(torch.as_tensor(U0).detach()[b:e], V0p, plan, model.n_components, wplan, dtype=model.factor_dtype)

@@ -31,7 +31,7 @@ def c4():
     plan = _engine.InteractionPlan(idx, val, m, n)
     R = random_sampler_device(n, m, S, seed=100, device=dev)
     wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r), n_items=n),
-                             item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)))
+                             item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)), n_components=r)
     assert wplan.user_chunks > 1 and wplan.n_slices > 1
     Dm = None
     st = _engine.TrainState(U0, V0, plan, r, wplan)

@@ -246,8 +246,12 @@ def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices):
     check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
 
 
-def test_wmrb_n_samples_beyond_lds_uses_global_workspace(tm):
-    """S = 30000 negatives per user: 240 KB of scores + D per user do not fit the 160 KB of LDS."""
+@pytest.mark.parametrize('forced_slices', [None, '3'])
+def test_wmrb_n_samples_beyond_lds_uses_global_workspace(tm, monkeypatch, forced_slices):
+    """S = 30000 negatives per user: 240 KB of scores + D per user do not fit the 160 KB of LDS.  Only the fused
+    pass has the global-workspace variant, so a catalog that would be sliced (here: forced) falls back to it."""
+    if forced_slices:
+        monkeypatch.setenv('TMF_ITEM_SLICES', forced_slices)
     rng = np.random.default_rng(3)
     m, n, r, S_ = 5, 40000, 8, 30000
     idx = np.stack([rng.integers(0, m, 60), rng.integers(0, n, 60)], axis=1)
@@ -257,7 +261,7 @@ def test_wmrb_n_samples_beyond_lds_uses_global_workspace(tm):
     V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
     R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
     model, t = check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
-    assert model._state.user_ws is not None
+    assert model._state.user_ws is not None and model._state.wplan.n_slices == 1
     assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
 
 
