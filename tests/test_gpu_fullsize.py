@@ -132,3 +132,32 @@ def test_full_size_mse_sampled_rows(c4):
         p = (st.U[u_ids[b:e], :r].to(torch.float64) * st.V[plan.col_u[b:e].to(torch.int64), :r].to(torch.float64)).sum(1)
         ref += float(((plan.val_u[b:e].to(torch.float64) - p) ** 2).sum())
     assert abs(float(loss[0]) - ref) <= 1e-5 * ref
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_full_catalog_fused_topk_matches_materialised_scores(dtype):
+    """predict at catalog scale (1,000,003 items - a ragged last tile, 512 MB of V, byte offsets up to 2^29 in the
+    kernel's buffer loads): the fused top-k of 300 users equals the stable top-k of the materialised score rows, and
+    the first / last items win when they should (planted maxima at both ends of the catalog)."""
+    from teamoflow_amd import _ops
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    n, m, r = 1_000_003, 300, (128 if dtype == 'f32' else 256)
+    V = torch.randn(n, r, device=dev, generator=g) * 0.1
+    U = torch.randn(m, r, device=dev, generator=g) * 0.1
+    V[0] = U[0] * 50                 # user 0's best item is the very first ...
+    V[n - 1] = U[1] * 50             # ... user 1's the very last (inside the ragged tile)
+    V[n - 2] = V[n - 1]              # and an exact tie right before it: the lower index must come first
+    if dtype == 'bf16':
+        U, V = U.to(torch.bfloat16), V.to(torch.bfloat16)
+    vals, idx = _ops.predict_topk(U, V, 10, return_values=True)
+    scores = U.float() @ V.float().T if dtype == 'bf16' else _ops.predict_gemm(U, V)
+    want = _ops.topk_stable(scores, 10)
+    if dtype == 'f32':
+        assert torch.equal(idx, want)
+    else:   # fp32 re-computation of bf16 products may differ in the last bit: compare by value, ties aside
+        got_v = torch.gather(scores, 1, idx.to(torch.int64))
+        want_v = torch.gather(scores, 1, want.to(torch.int64))
+        assert rel_err(got_v.cpu().numpy(), want_v.cpu().numpy()) < 1e-5
+    assert int(idx[0, 0]) == 0 and idx[1, :2].tolist() == [n - 2, n - 1]
+    assert rel_err(vals.cpu().numpy(), torch.gather(scores, 1, idx.to(torch.int64)).cpu().numpy()) < 1e-5
