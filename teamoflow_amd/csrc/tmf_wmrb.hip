@@ -20,9 +20,48 @@ constexpr int kUnrollW = 4;
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
-// cnt += (x >= 0): compare into VCC, add it as the carry-in (2 VALU instead of cmp + cndmask + add)
-__device__ __forceinline__ void count_ge0(int& cnt, float x) {
-    asm("v_cmp_le_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(x) : "vcc");
+// Length of the scores row as the hinge loops see it: the eight half-waves of a block sweep an eighth each, two float4
+// per step, so the row is padded with -inf (terms that add 0 and never count) to 8 equal parts of an even number of
+// float4 - the loops then have one wave-uniform trip count and no tail handling.
+__host__ __device__ inline int sp_padded(int S) {
+    const int nf4 = (S + 3) / 4;
+    const int per = ((nf4 + 2 * kWaves - 1) / (2 * kWaves) + 1) & ~1;
+    return 4 * 2 * kWaves * per;
+}
+
+// c0 += [x0 >= 0] + [x2 >= 0], c1 += [x1 >= 0] + [x3 >= 0]: four compares into four SGPR pairs, then four adds that take
+// them as carry-in (2 VALU per term instead of cmp + cndmask + add).  Every reader is three instructions behind its
+// writer: gfx940+ needs two wait states between a VALU that writes an SGPR and a VALU that reads it.
+__device__ __forceinline__ void count_ge0_x4(int& c0, int& c1, float x0, float x1, float x2, float x3) {
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_le_f32_e64 %2, 0, %6\n\t"
+        "v_cmp_le_f32_e64 %3, 0, %7\n\t"
+        "v_cmp_le_f32_e64 %4, 0, %8\n\t"
+        "v_cmp_le_f32_e64 %5, 0, %9\n\t"
+        "v_addc_co_u32_e64 %0, %2, 0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %1, %3, 0, %1, %3\n\t"
+        "v_addc_co_u32_e64 %0, %4, 0, %0, %4\n\t"
+        "v_addc_co_u32_e64 %1, %5, 0, %1, %5"
+        : "+v"(c0), "+v"(c1), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+}
+
+// r_i = (sps >= -c_i) ? w_i : 0 for four (c, w) pairs, compares first, selects after (same SGPR hazard rule; the
+// compiler's own sequence pads every compare / select pair with s_nop).
+__device__ __forceinline__ float4 select_ge_x4(float sps, const float4 c, const float4 w) {
+    unsigned long long m0, m1, m2, m3;
+    float4 r;
+    asm("v_cmp_ge_f32_e64 %4, %8, -%9\n\t"
+        "v_cmp_ge_f32_e64 %5, %8, -%10\n\t"
+        "v_cmp_ge_f32_e64 %6, %8, -%11\n\t"
+        "v_cmp_ge_f32_e64 %7, %8, -%12\n\t"
+        "v_cndmask_b32_e64 %0, 0, %13, %4\n\t"
+        "v_cndmask_b32_e64 %1, 0, %14, %5\n\t"
+        "v_cndmask_b32_e64 %2, 0, %15, %6\n\t"
+        "v_cndmask_b32_e64 %3, 0, %16, %7"
+        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(sps), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w), "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w));
+    return r;
 }
 
 // SLICED = true is the middle kernel of the sliced user pass (see k_wmrb_slice below): sp[u, :] comes from
@@ -42,9 +81,9 @@ __device__ __forceinline__ void wmrb_user_body(
     constexpr int NG = 64 / G;          // groups per wave
     constexpr int NGB = NG * kWaves;    // groups per block
     constexpr int LD = 4 * G * NV;
-    const int S4 = round4(S);
-    float* sp = BIG ? sp_ws + u * (int64_t)S4 : reinterpret_cast<float*>(smem_raw);   // [S4] scores, tail -inf
-    float* Dl = BIG ? Dg + u * (int64_t)S : sp + S4;                                   // [S]  D[u, :]
+    const int S4 = round4(S), SP = sp_padded(S);
+    float* sp = BIG ? sp_ws + u * (int64_t)SP : reinterpret_cast<float*>(smem_raw);   // [SP] scores, tail -inf
+    float* Dl = BIG ? Dg + u * (int64_t)S : sp + SP;                                   // [S]  D[u, :]
     float* c1 = BIG ? reinterpret_cast<float*>(smem_raw) : Dl + S4;  // [kPosChunk] 1 - p_k, -inf for non-positives
     float* wl = c1 + kPosChunk;                       // [kPosChunk] w_k
     float* dl = wl + kPosChunk;                       // [kPosChunk] delta_k
@@ -99,7 +138,7 @@ __device__ __forceinline__ void wmrb_user_body(
                 if (g == 0 && s < S) sp[s] = d;
             }
         }
-        for (int s = tid; s < S4; s += kThreads) {
+        for (int s = tid; s < SP; s += kThreads) {
             if (s < S) Dl[s] = 0.f;
             else sp[s] = -INFINITY;
         }
@@ -140,20 +179,18 @@ __device__ __forceinline__ void wmrb_user_body(
             // partials are combined in fixed order.
             {
                 constexpr int kSG = 2 * kWaves;  // sample groups = half-waves of the block
-                const int nf4 = S4 / 4, per_sg = (nf4 + kSG - 1) / kSG;
+                const int per_sg = SP / (4 * kSG);  // float4 per sample group: even, the same for every group
                 const int sg = wave * 2 + (lane >> 5), l32 = lane & 31;
-                const int f_beg = sg * per_sg;
-                const int f_end = (f_beg + per_sg < nf4) ? f_beg + per_sg : nf4;
-                const float4* sp4 = reinterpret_cast<const float4*>(sp);
-                const float4 ninf4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                const float4* sp4 = reinterpret_cast<const float4*>(sp) + sg * per_sg;
                 for (int kb = 0; kb < len; kb += 32) {
                     const int kk = kb + l32;
                     const float c1v = (kk < len) ? c1[kk] : -INFINITY;  // -inf: every term is 0 and never counts
                     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-                    int cnt = 0;
-                    for (int f = f_beg; f < f_end; f += 2) {
+                    int cnt = 0, cnt2 = 0;
+#pragma unroll 2
+                    for (int f = 0; f < per_sg; f += 2) {
                         const float4 q = sp4[f];
-                        const float4 q2 = (f + 1 < f_end) ? sp4[f + 1] : ninf4;
+                        const float4 q2 = sp4[f + 1];
                         const float x0 = c1v + q.x, x1 = c1v + q.y, x2 = c1v + q.z, x3 = c1v + q.w;
                         const float x4 = c1v + q2.x, x5 = c1v + q2.y, x6 = c1v + q2.z, x7 = c1v + q2.w;
                         m0 += fmaxf(x0, 0.f);
@@ -164,15 +201,10 @@ __device__ __forceinline__ void wmrb_user_body(
                         m1 += fmaxf(x5, 0.f);
                         m2 += fmaxf(x6, 0.f);
                         m3 += fmaxf(x7, 0.f);
-                        count_ge0(cnt, x0);
-                        count_ge0(cnt, x1);
-                        count_ge0(cnt, x2);
-                        count_ge0(cnt, x3);
-                        count_ge0(cnt, x4);
-                        count_ge0(cnt, x5);
-                        count_ge0(cnt, x6);
-                        count_ge0(cnt, x7);
+                        count_ge0_x4(cnt, cnt2, x0, x1, x2, x3);
+                        count_ge0_x4(cnt, cnt2, x4, x5, x6, x7);
                     }
+                    cnt += cnt2;
                     pm[sg * 32 + l32] = (m0 + m1) + (m2 + m3);
                     pc[sg * 32 + l32] = cnt;
                     __syncthreads();
@@ -207,11 +239,11 @@ __device__ __forceinline__ void wmrb_user_body(
                 const float4* w4 = reinterpret_cast<const float4*>(wl);
 #pragma unroll 4
                 for (int q = 0; q < len4 / 4; ++q) {
-                    const float4 cc = c4[q], ww = w4[q];
-                    d0 += (sps >= -cc.x) ? ww.x : 0.f;
-                    d1 += (sps >= -cc.y) ? ww.y : 0.f;
-                    d0 += (sps >= -cc.z) ? ww.z : 0.f;
-                    d1 += (sps >= -cc.w) ? ww.w : 0.f;
+                    const float4 r = select_ge_x4(sps, c4[q], w4[q]);
+                    d0 += r.x;
+                    d1 += r.y;
+                    d0 += r.z;
+                    d1 += r.w;
                 }
                 Dl[s] += d0 + d1;
             }
@@ -299,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_user(
 
 static size_t wmrb_user_lds(int S, int ld, bool big, bool sliced = false) {
     // sp + D (unless in global memory), c1 / w / delta / item per chunk entry, the user's negatives, the reduction
-    return sizeof(float) * ((big ? 0 : (size_t)2 * round4(S)) + 4 * kPosChunk +
+    return sizeof(float) * ((big ? 0 : (size_t)sp_padded(S) + round4(S)) + 4 * kPosChunk +
                             ((sliced || big) ? 0 : (size_t)round4(S)) + 2 * kWaves * 64 + (size_t)kWaves * ld + 2 * kWaves);
 }
 
@@ -484,7 +516,7 @@ extern "C" size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int 
     const RowGeom geom = row_geom(n_components);
     if (geom.ld == 0 || S <= 0 || n_users <= 0) return 0;
     if (wmrb_user_lds(S, geom.ld, false) <= 160 * 1024) return 0;
-    return (size_t)n_users * round4(S) * sizeof(float);
+    return (size_t)n_users * sp_padded(S) * sizeof(float);
 }
 
 template <typename T>

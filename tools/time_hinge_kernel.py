@@ -20,10 +20,13 @@ p, w = plan, wplan
 for _ in range(2):
     _engine.epoch_wmrb(st, adam, n / S, loss)
 torch.cuda.synchronize()
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-ev[0].record()
-for _ in range(5):
-    _lib.check(lib.tmf_wmrb_hinge_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.sp), i32(m), i32(S), n / S,
-                                      _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.gpos), _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), r, _lib.stream_ptr()), lib)
-ev[1].record(); torch.cuda.synchronize()
-print(os.environ.get('TMF_LIB'), 'hinge ms', ev[0].elapsed_time(ev[1]) / 5)
+# the kernel with fewer samples per user than the tables hold (same buffers, smaller rows): what is left at S -> 0 is the
+# per-positive work (row gathers of V[j_k], dot products, the gpos accumulation) and the per-user overhead
+for S_eff in (S, 512, 256, 64, 16):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(5):
+        _lib.check(lib.tmf_wmrb_hinge_f32(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.sp), i32(m), i32(S_eff), n / S,
+                                          _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.gpos), _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), r, _lib.stream_ptr()), lib)
+    ev[1].record(); torch.cuda.synchronize()
+    print(os.environ.get('TMF_LIB'), f'hinge S={S_eff}: {ev[0].elapsed_time(ev[1]) / 5:.2f} ms')
