@@ -208,6 +208,9 @@ def small_configs(dev, quick=False):
                          loss_rel_diff_first_epochs=float(np.abs(np.array(model.loss_history_[:k]) - ref['loss'][:k]).max()
                                                           / np.abs(ref['loss'][:k]).max()),
                          recall_at_10=float(model.recall_at_k(torch.tensor(A)).mean()))
+        if cpu_epochs == epochs:  # the CPU restatement ran the whole fit: end-to-end recall@10 parity (BASELINE: within 1e-3)
+            want = float(dense_ref.recall_at_k_dense(ref['U'], ref['V'], A, 10).mean())
+            out[name].update(recall_at_10_cpu_restatement=want, recall_at_10_abs_diff=abs(out[name]['recall_at_10'] - want))
         log(f'[bench] {name}: {out[name]}')
     return out
 
@@ -391,10 +394,16 @@ def main():
                                + ('(tmf_predict_topk_bf16: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)' if args.dtype == 'bf16'
                                   else '(tmf_predict_topk_f32: exact-fp32 MFMA, peak 157.3 TF)'))
         got, want = recall_parity(dev)
-        out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want), case='C1 golden fixture')
+        out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want),
+                                   case='C1 golden fixture: ranking of the oracle-trained tables (450 epochs)')
     if rank == 0 and world == 1 and (args.small_configs or not args.no_extras):
         # the reference's own (dense, full-batch) formulation on the host cores next to the engine, BASELINE configs 1-3
         out['reference_formulation_cpu'] = small_configs(dev, quick=not args.small_configs)
+        c2 = out['reference_formulation_cpu'].get('C2', {})
+        if 'recall_at_10_abs_diff' in c2 and 'recall_at_10' in out:
+            out['recall_at_10']['end_to_end_C2'] = dict(engine=c2['recall_at_10'], oracle=c2['recall_at_10_cpu_restatement'],
+                                                        abs_diff=c2['recall_at_10_abs_diff'],
+                                                        case='C2 (943 x 1682, r=32, MSE): 100 epochs trained by each side from the same start')
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
     if dp_mode:
