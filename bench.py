@@ -211,6 +211,22 @@ def small_configs(dev, quick=False):
         if cpu_epochs == epochs:  # the CPU restatement ran the whole fit: end-to-end recall@10 parity (BASELINE: within 1e-3)
             want = float(dense_ref.recall_at_k_dense(ref['U'], ref['V'], A, 10).mean())
             out[name].update(recall_at_10_cpu_restatement=want, recall_at_10_abs_diff=abs(out[name]['recall_at_10'] - want))
+        if loss == 'wmrb' and not quick:
+            # end-to-end WMRB parity: 20 epochs by the engine and by the C/OpenMP closed-form restatement from the same start
+            from oracle import sparse_c
+            sparse_c.set_threads(host_cores())
+            e2e = 20
+            plan_c = sparse_c.Plan(idx, val, m, n, R)
+            Uc, Vc, closs = U0, V0, []
+            for _ in range(e2e):
+                Uc, Vc, mean, _t = sparse_c.wmrb_epoch(Uc, Vc, plan_c, n, S, lr, want_grads=False)
+                closs.append(mean)
+            model.fit(e2e, eye(m), eye(n), inter, lr=lr)
+            got = float(model.recall_at_k(torch.tensor(A)).mean())
+            want = float(dense_ref.recall_at_k_dense(Uc, Vc, A, 10).mean())
+            out[name]['end_to_end_20_epochs'] = dict(
+                recall_at_10_engine=got, recall_at_10_c_restatement=want, abs_diff=abs(got - want),
+                loss_rel_diff=float(np.abs(np.array(model.loss_history_) - np.array(closs)).max() / np.abs(closs).max()))
         log(f'[bench] {name}: {out[name]}')
     return out
 
