@@ -623,7 +623,7 @@ def test_two_ranks_on_one_card_match_single_process(tmp_path, loss):
     assert res['V1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('TMF_FUZZ_SEEDS', '12'))))   # TMF_FUZZ_SEEDS=300 for a soak run
 def test_randomized_shapes_against_oracle(tm, monkeypatch, seed):
     """Random small problems: ragged / empty rows, mixed-sign values, every path selector (fused or sliced
     user pass, user-blocked item lists, fp32 or bf16-free) - one step each against the fp64 closed form."""
@@ -740,3 +740,25 @@ def test_runs_are_bit_reproducible(tm, golden):
     b = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 5, 0.1, 'wmrb', g['R'], 100, 50)
     assert torch.equal(a.user_embedding, b.user_embedding) and torch.equal(a.item_embedding, b.item_embedding)
     assert a.loss_history_ == b.loss_history_
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('TMF_FUZZ_SEEDS', '12'))))
+def test_randomized_fused_topk(tm, seed):
+    """Random (users, items, rank, k) incl. ranks that take every staging mode (K % 4 != 0, K % 32 != 0), small-integer
+    factors (many exact ties across tiles), clamping, fp32 and bf16: fused top-k == stable top-k of the materialised scores."""
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(7000 + seed)
+    m, n = int(rng.integers(1, 400)), int(rng.integers(1, 3000))
+    r = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128]))
+    k = int(min(n, rng.choice([1, 2, 5, 10, 17, 32])))
+    span = int(rng.choice([1, 2, 4]))
+    U = rng.integers(-span, span + 1, (m, r)).astype(np.float32)
+    V = rng.integers(-span, span + 1, (n, r)).astype(np.float32)
+    sc = U @ V.T                                        # exact in fp32 and in bf16 products / fp32 sums
+    clamp = bool(rng.integers(0, 2))
+    ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
+    got = tm.ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp).cpu().numpy()
+    assert np.array_equal(got, ref), (m, n, r, k, clamp, 'f32')
+    gb = tm.ops.predict_topk(torch.tensor(U).to(torch.bfloat16).cuda(), torch.tensor(V).to(torch.bfloat16).cuda(), k,
+                             clamp_negatives=clamp).cpu().numpy()
+    assert np.array_equal(gb, ref), (m, n, r, k, clamp, 'bf16')
