@@ -279,7 +279,7 @@ __device__ __forceinline__ void wmrb_user_body(
             for (int t = 0; t < kUnrollW; ++t) axpy<NV>(acc, d[t], y[t]);
         }
         if (!BIG)
-            for (int s = tid; s < S; s += kThreads) Dg[u * (int64_t)S + s] = Dl[s];
+            for (int s = tid; s < S; s += kThreads) __builtin_nontemporal_store(Dl[s], Dg + u * (int64_t)S + s);
     }
 
     // ---- block reduction of gU (groups of a wave, then the four waves in order) and of the loss ----
@@ -443,7 +443,7 @@ __device__ __forceinline__ void wmrb_slice_body(
                         if (g == (e & (G - 1))) keep = p;
                         // a full run of G scores (or the tail of the tile): one contiguous 4*G-byte store per group
                         if (e < cnt && ((e & (G - 1)) == G - 1 || e == cnt - 1)) {
-                            if (g <= (e & (G - 1))) sp[u * (int64_t)S + t0 + (e & ~(G - 1)) + g] = keep;
+                            if (g <= (e & (G - 1))) __builtin_nontemporal_store(keep, sp + u * (int64_t)S + t0 + (e & ~(G - 1)) + g);
                         }
                     }
                 }
