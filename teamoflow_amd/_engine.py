@@ -150,11 +150,11 @@ class InteractionPlan:
 SLAB_BUDGET = int(os.environ.get('TMF_SLAB_BUDGET', 8 << 30))  # bytes of per-(user block, item) partial rows
 
 
-def default_user_chunks(n_users, ld, target_bytes=4 << 20, n_items=None):
+def default_user_chunks(n_users, ld, target_bytes=3 << 20, n_items=None):
     """Number of user blocks the WMRB item lists are cut into so that the U rows the lists of one block
-    gather (n_users / chunks * ld * 4 bytes, ~one XCD L2) stay cache-resident while that block is processed.
-    Measured at C4 (1M users, 512-byte rows), item pass ms with LDS-staged entries: 32 blocks 72.0, 64 -> 57.7,
-    128 -> 42.6, 256 -> 41.6, 512 -> 54.1 (profiles/r01_user_chunk_sweep.txt)."""
+    gather (n_users / chunks * ld * 4 bytes, most of one XCD L2) stay cache-resident while that block is processed.
+    Measured at C4 (1M users, 512-byte rows), item pass ms: 48 blocks 69.7, 64 -> 60.4, 96 -> 45.2, 123 -> 35.8,
+    160 -> 33.8, 256 -> 33.7 (profiles/r01_user_chunk_sweep.txt; with non-temporal partial-row stores)."""
     env = os.environ.get('TMF_USER_CHUNKS')
     if env:
         return max(1, int(env))

@@ -152,10 +152,14 @@ __device__ __forceinline__ void load_row(Frag<NV>& f, const __bf16* __restrict__
     }
 }
 
-// Every row this engine writes (new table rows, slab partials, raw gradients, per-slice partials) is written once and
-// read by a LATER kernel, while the same kernel re-reads a cache-sized window of other rows hundreds of times.  Plain
-// stores allocate in L2 and evict that window (measured on the C4 item pass: 43.6 ms, 35.8 ms with non-temporal slab
-// stores), so all row stores are non-temporal.
+// Row stores.  Every row this engine writes (new table rows, slab partials, raw gradients, per-slice partials) is written
+// once and read by a LATER kernel, so the stores carry the non-temporal hint.  Measured on one box, same run: the hint
+// itself changes nothing (item pass at C4 36.8 ms without, 36.6 ms with); what took that kernel from 44.0 to 36.8 ms was
+// the code the compiler emits around this helper - with the previous `*(float4*)p = v` form it waited for each of the
+// four unrolled row loads of the gather loop before issuing the next (one row in flight per lane group).  Check the
+// ISA of k_wsum_pass for `global_load_dwordx4` directly followed by `s_waitcnt vmcnt(0)` after touching this file
+// (profiles/r01_sliced_user_pass.txt has the same-box numbers, including the variant that loads into raw registers and
+// converts / selects afterwards in every gather loop: slower on C4, 3 % faster on the config-5 shard - not kept).
 typedef float tmf_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_f4_nt(float* p, const float4& v) {
     const tmf_f4 t = {v.x, v.y, v.z, v.w};

@@ -203,5 +203,5 @@ def test_item_slices_and_defaults_on_cpu():
     # defaults: small catalogs keep the fused pass / a single user block; C4 gets 13 slices and 123 blocks
     assert _engine.default_item_slices(1682, 32) == 1 and _engine.default_user_chunks(943, 32, n_items=1682) == 1
     assert _engine.default_item_slices(100_000, 128) == 13
-    assert _engine.default_user_chunks(1_000_000, 128, n_items=100_000) == 123
+    assert _engine.default_user_chunks(1_000_000, 128, n_items=100_000) == 163   # 3 MB blocks
     assert _engine.default_user_chunks(1_250_000, 256, n_items=1_000_000) == 8   # slab budget bounds it
