@@ -424,13 +424,21 @@ __device__ __forceinline__ void wmrb_slice_body(
             for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
                 Frag<NV> y[kUnrollW];
                 float d[kUnrollW];
+                // the four ids (and weights) of this step in ONE LDS read each (e0 % 4 == 0, 16-byte aligned tile buffers;
+                // slots past cnt hold stale values and are never used): one LDS round trip before the four row loads
+                // instead of four dependent ones
+                static_assert(kUnrollW == 4, "vector LDS reads assume four entries per step");
+                const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);
+                const float4 w4 = GRADU ? *reinterpret_cast<const float4*>(dst + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int idv[4] = {id4.x, id4.y, id4.z, id4.w};
+                const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
                 for (int t = 0; t < kUnrollW; ++t) {
                     const int e = e0 + t;
                     bool want = e < cnt;
                     d[t] = 0.f;
-                    if (GRADU && want) { d[t] = dst[e]; want = d[t] != 0.f; }
-                    if (want) load_row<G, NV>(y[t], V, ids[e], g);
+                    if (GRADU && want) { d[t] = wv[t]; want = d[t] != 0.f; }
+                    if (want) load_row<G, NV>(y[t], V, idv[t], g);
                     else zero<NV>(y[t]);
                 }
 #pragma unroll
