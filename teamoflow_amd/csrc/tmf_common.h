@@ -152,6 +152,58 @@ __device__ __forceinline__ void load_row(Frag<NV>& f, const __bf16* __restrict__
     }
 }
 
+// What the load instructions of a row return, before any arithmetic touches it.  The gather loops fill kUnroll Raw
+// registers (row or zeros) first and convert afterwards: a bf16 -> fp32 conversion placed right after a load makes the
+// compiler wait for that load before issuing the next one (one row in flight per lane group instead of kUnroll).
+template <int NV, typename T>
+struct Raw;
+template <int NV>
+struct Raw<NV, float> {
+    float4 v[NV];
+};
+template <int NV>
+struct Raw<NV, __bf16> {
+    bf16x8 v[NV / 2];
+};
+template <int G, int NV>
+__device__ __forceinline__ void load_raw(Raw<NV, float>& r, const float* __restrict__ T, int64_t row, int g) {
+    const float4* p = reinterpret_cast<const float4*>(T + row * (int64_t)(4 * G * NV)) + g;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) r.v[v] = p[G * v];
+}
+template <int G, int NV>
+__device__ __forceinline__ void load_raw(Raw<NV, __bf16>& r, const __bf16* __restrict__ T, int64_t row, int g) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(T + row * (int64_t)(4 * G * NV)) + g;
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv) r.v[pv] = p[G * pv];
+}
+template <int NV>
+__device__ __forceinline__ void zero_raw(Raw<NV, float>& r) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) r.v[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int NV>
+__device__ __forceinline__ void zero_raw(Raw<NV, __bf16>& r) {
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[pv][e] = (__bf16)0.0f;
+}
+template <int NV>
+__device__ __forceinline__ void to_frag(Frag<NV>& f, const Raw<NV, float>& r) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) f.v[v] = r.v[v];
+}
+template <int NV>
+__device__ __forceinline__ void to_frag(Frag<NV>& f, const Raw<NV, __bf16>& r) {
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv) {
+        const f32x8 w = __builtin_convertvector(r.v[pv], f32x8);
+        f.v[2 * pv] = make_float4(w[0], w[1], w[2], w[3]);
+        f.v[2 * pv + 1] = make_float4(w[4], w[5], w[6], w[7]);
+    }
+}
+
 // Row stores.  Every row this engine writes (new table rows, slab partials, raw gradients, per-slice partials) is written
 // once and read by a LATER kernel, so the stores carry the non-temporal hint.  Measured on one box, same run: the hint
 // itself changes nothing (item pass at C4 36.8 ms without, 36.6 ms with); what took that kernel from 44.0 to 36.8 ms was

@@ -2,6 +2,7 @@
 // gather-sum used by the WMRB item side, the combine of multi-segment rows, the standalone
 // fresh-Adam row update and the deterministic loss sum.  See include/tmf.h for the contracts
 // and DESIGN.md for the bytes each kernel moves.
+#include <type_traits>
 #include "tmf_common.h"
 
 namespace tmf {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
     float lsum = 0.f;
 
     for (int64_t k0 = beg + grp; k0 < end; k0 += (int64_t)NG * kUnroll) {
-        Frag<NV> y[kUnroll];
+        Raw<NV, T> raw[kUnroll];
         float a[kUnroll];
         int j[kUnroll];
         bool ok[kUnroll];
@@ -62,19 +63,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
         }
 #pragma unroll
         for (int t = 0; t < kUnroll; ++t) {
-            if (ok[t]) {
-                load_row<G, NV>(y[t], Y_old, j[t], g);
-            } else {
-                a[t] = 0.f;
-                zero<NV>(y[t]);
-            }
+            load_raw<G, NV>(raw[t], Y_old, j[t], g);  // padded slots re-read the segment's last entry; masked below
         }
 #pragma unroll
         for (int t = 0; t < kUnroll; ++t) {
-            const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
-            const float e = a[t] - p;          // padded slots: a = 0, y = 0 -> e = 0
+            Frag<NV> y;
+            to_frag<NV>(y, raw[t]);
+            const float p = group_allsum<G>(dot_partial<NV>(x, y));
+            const float e = ok[t] ? a[t] - p : 0.f;  // padded slots contribute nothing
             lsum += e * e;
-            axpy<NV>(acc, -2.0f * e, y[t]);
+            axpy<NV>(acc, -2.0f * e, y);
         }
     }
     across_groups_sum<G, NV>(acc);
@@ -129,17 +127,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
         }
         // lane group `grp` takes entries grp, grp + NG, ...; a row is only loaded when its weight is not 0
         for (int e0 = grp; e0 < cnt; e0 += NG * kUnroll) {
-            Frag<NV> y[kUnroll];
+            Raw<NV, T> raw[kUnroll];
             float wc[kUnroll];
 #pragma unroll
             for (int t = 0; t < kUnroll; ++t) {
                 const int e = e0 + t * NG;
                 wc[t] = (e < cnt) ? ws[e] : 0.f;
-                if (wc[t] != 0.f) load_row<G, NV>(y[t], Tab, ids[e], g);
-                else zero<NV>(y[t]);
+                if constexpr (std::is_same<T, float>::value) {
+                    // fp32: skipping the load of a zero-weight row measured 0.7 ms faster at C4 than the branch-free form
+                    if (wc[t] != 0.f) load_raw<G, NV>(raw[t], Tab, ids[e], g);
+                    else zero_raw<NV>(raw[t]);
+                } else {
+                    // bf16: no branch around the load (a zero weight reads the tile's first row, an L1 hit, and multiplies it
+                    // by 0) - with a branch the compiler waits for every load before issuing the next
+                    load_raw<G, NV>(raw[t], Tab, ids[wc[t] != 0.f ? e : 0], g);
+                }
             }
 #pragma unroll
-            for (int t = 0; t < kUnroll; ++t) axpy<NV>(acc, wc[t], y[t]);
+            for (int t = 0; t < kUnroll; ++t) {
+                Frag<NV> y;
+                to_frag<NV>(y, raw[t]);
+                axpy<NV>(acc, wc[t], y);
+            }
         }
     }
     across_groups_sum<G, NV>(acc);

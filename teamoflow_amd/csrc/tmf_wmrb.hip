@@ -124,17 +124,18 @@ __device__ __forceinline__ void wmrb_user_body(
         const int32_t* Ri = BIG ? Ru : Rl;
         if (!SLICED)
         for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
-            Frag<NV> y[kUnrollW];
+            Raw<NV, T> raw[kUnrollW];
 #pragma unroll
             for (int t = 0; t < kUnrollW; ++t) {
                 const int s = s0 + t * NGB;
-                if (s < S) load_row<G, NV>(y[t], V_old, Ri[s], g);
-                else zero<NV>(y[t]);
+                load_raw<G, NV>(raw[t], V_old, Ri[s < S ? s : 0], g);
             }
 #pragma unroll
             for (int t = 0; t < kUnrollW; ++t) {
                 const int s = s0 + t * NGB;
-                const float d = group_allsum<G>(dot_partial<NV>(x, y[t]));
+                Frag<NV> y;
+                to_frag<NV>(y, raw[t]);
+                const float d = group_allsum<G>(dot_partial<NV>(x, y));
                 if (g == 0 && s < S) sp[s] = d;
             }
         }
@@ -152,20 +153,21 @@ __device__ __forceinline__ void wmrb_user_body(
             for (int kk = tid; kk < len; kk += kThreads) ci[kk] = (val[cb + kk] > 0.f) ? col[cb + kk] : -1;
             __syncthreads();
             for (int k0 = gid; k0 < len; k0 += NGB * kUnrollW) {
-                Frag<NV> y[kUnrollW];
+                Raw<NV, T> raw[kUnrollW];
                 bool pos[kUnrollW];
 #pragma unroll
                 for (int t = 0; t < kUnrollW; ++t) {
                     const int kk = k0 + t * NGB;
                     const int item = (kk < len) ? ci[kk] : -1;
                     pos[t] = item >= 0;
-                    if (pos[t]) load_row<G, NV>(y[t], V_old, item, g);
-                    else zero<NV>(y[t]);
+                    load_raw<G, NV>(raw[t], V_old, pos[t] ? item : 0, g);
                 }
 #pragma unroll
                 for (int t = 0; t < kUnrollW; ++t) {
                     const int kk = k0 + t * NGB;
-                    const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
+                    Frag<NV> y;
+                    to_frag<NV>(y, raw[t]);
+                    const float p = group_allsum<G>(dot_partial<NV>(x, y));
                     if (g == 0 && kk < len) c1[kk] = pos[t] ? (1.0f - p) : -INFINITY;
                 }
             }
@@ -249,34 +251,40 @@ __device__ __forceinline__ void wmrb_user_body(
             }
             // 2d
             for (int k0 = gid; k0 < len; k0 += NGB * kUnrollW) {
-                Frag<NV> y[kUnrollW];
+                Raw<NV, T> raw[kUnrollW];
                 float d[kUnrollW];
 #pragma unroll
                 for (int t = 0; t < kUnrollW; ++t) {
                     const int kk = k0 + t * NGB;
                     d[t] = (kk < len) ? dl[kk] : 0.f;
-                    if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, ci[kk], g);
-                    else zero<NV>(y[t]);
+                    load_raw<G, NV>(raw[t], V_old, d[t] != 0.f ? ci[kk] : 0, g);
                 }
 #pragma unroll
-                for (int t = 0; t < kUnrollW; ++t) axpy<NV>(acc, d[t], y[t]);
+                for (int t = 0; t < kUnrollW; ++t) {
+                    Frag<NV> y;
+                    to_frag<NV>(y, raw[t]);
+                    axpy<NV>(acc, d[t], y);
+                }
             }
             __syncthreads();
         }
         // ---- phase 3 ----
         if (!SLICED)
         for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
-            Frag<NV> y[kUnrollW];
+            Raw<NV, T> raw[kUnrollW];
             float d[kUnrollW];
 #pragma unroll
             for (int t = 0; t < kUnrollW; ++t) {
                 const int s = s0 + t * NGB;
                 d[t] = (s < S) ? Dl[s] : 0.f;
-                if (d[t] != 0.f) load_row<G, NV>(y[t], V_old, Ri[s], g);
-                else zero<NV>(y[t]);
+                load_raw<G, NV>(raw[t], V_old, d[t] != 0.f ? Ri[s] : 0, g);
             }
 #pragma unroll
-            for (int t = 0; t < kUnrollW; ++t) axpy<NV>(acc, d[t], y[t]);
+            for (int t = 0; t < kUnrollW; ++t) {
+                Frag<NV> y;
+                to_frag<NV>(y, raw[t]);
+                axpy<NV>(acc, d[t], y);
+            }
         }
         if (!BIG)
             for (int s = tid; s < S; s += kThreads) __builtin_nontemporal_store(Dl[s], Dg + u * (int64_t)S + s);
@@ -422,7 +430,7 @@ __device__ __forceinline__ void wmrb_slice_body(
             }
             float keep = 0.f;  // scores: lane g keeps the score of entry (e & (G-1)) == g until G of them are complete
             for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
-                Frag<NV> y[kUnrollW];
+                Raw<NV, T> raw[kUnrollW];
                 float d[kUnrollW];
                 // the four ids (and weights) of this step in ONE LDS read each (e0 % 4 == 0, 16-byte aligned tile buffers;
                 // slots past cnt hold stale values and are never used): one LDS round trip before the four row loads
@@ -438,16 +446,17 @@ __device__ __forceinline__ void wmrb_slice_body(
                     bool want = e < cnt;
                     d[t] = 0.f;
                     if (GRADU && want) { d[t] = wv[t]; want = d[t] != 0.f; }
-                    if (want) load_row<G, NV>(y[t], V, idv[t], g);
-                    else zero<NV>(y[t]);
+                    load_raw<G, NV>(raw[t], V, want ? idv[t] : 0, g);
                 }
 #pragma unroll
                 for (int t = 0; t < kUnrollW; ++t) {
+                    Frag<NV> y;
+                    to_frag<NV>(y, raw[t]);
                     if (GRADU) {
-                        axpy<NV>(acc, d[t], y[t]);
+                        axpy<NV>(acc, d[t], y);
                     } else {
                         const int e = e0 + t;
-                        const float p = group_allsum<G>(dot_partial<NV>(x, y[t]));
+                        const float p = group_allsum<G>(dot_partial<NV>(x, y));
                         if (g == (e & (G - 1))) keep = p;
                         // a full run of G scores (or the tail of the tile): one contiguous 4*G-byte store per group
                         if (e < cnt && ((e & (G - 1)) == G - 1 || e == cnt - 1)) {
