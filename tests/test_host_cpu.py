@@ -177,7 +177,7 @@ def test_generic_path_matches_oracle_on_cpu(golden):
     assert np.abs(np.array(model.loss_history_) - g['loss'][:5]).max() / g['loss'][0] < 1e-6
 
 
-def test_item_slices_and_defaults_on_cpu():
+def test_item_slices_and_defaults_on_cpu(monkeypatch):
     from teamoflow_amd import _engine
     from teamoflow_amd._engine import InteractionPlan, WmrbPlan
     rng = np.random.default_rng(4)
@@ -201,11 +201,10 @@ def test_item_slices_and_defaults_on_cpu():
     w.D.copy_(torch.tensor(Rs.astype(np.float32)))                      # pretend D[u, s] = item id of the sorted slot
     assert np.array_equal(w.D_in_model_order().numpy(), R.astype(np.float32))
     # defaults: small catalogs keep the fused pass / a single user block; C4 gets 13 slices and 163 blocks
-    os.environ['TMF_SLAB_BUDGET'] = str(8 << 30)
+    monkeypatch.setenv('TMF_SLAB_BUDGET', str(8 << 30))
     assert _engine.default_item_slices(1682, 32) == 1 and _engine.default_user_chunks(943, 32, n_items=1682) == 1
     assert _engine.default_item_slices(100_000, 128) == 13
     assert _engine.default_user_chunks(1_000_000, 128, n_items=100_000) == 163   # 3 MB blocks
     assert _engine.default_user_chunks(1_250_000, 256, n_items=1_000_000) == 8   # an 8 GB slab budget bounds it
-    os.environ['TMF_SLAB_BUDGET'] = str(64 << 30)
+    monkeypatch.setenv('TMF_SLAB_BUDGET', str(64 << 30))
     assert _engine.default_user_chunks(1_250_000, 256, n_items=1_000_000) == 67
-    del os.environ['TMF_SLAB_BUDGET']
