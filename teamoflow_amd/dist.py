@@ -167,7 +167,12 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
     ld = _lib.padded_ld(model.n_components, model.factor_dtype)
     wplan, c = None, 0.0
     if wmrb:
-        R = torch.as_tensor(model.random_ind)[b:e].to(device=dev, dtype=torch.int32).contiguous()
+        Rall = torch.as_tensor(model.random_ind)
+        if Rall.dim() != 2 or Rall.shape[0] != n_users:
+            raise ValueError(f'random_ind has shape {tuple(Rall.shape)}, expected [{n_users}, n_samples]')
+        R = Rall[b:e].to(device=dev, dtype=torch.int32).contiguous()
+        if R.numel() and (int(R.min()) < 0 or int(R.max()) >= n_items):
+            raise IndexError('random_ind holds item ids outside [0, n_items)')
         c = model.n_items / model.n_samples
         wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(e - b, ld, n_items=n_pad),
                                  item_slices=_engine.default_item_slices(n_pad, ld), n_components=model.n_components)
