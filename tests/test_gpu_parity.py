@@ -591,8 +591,9 @@ def test_midsize_against_c_oracle(tm, monkeypatch, slices):
         assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], 1e-2, what='mse V')
 
 
-@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
-def test_two_ranks_on_one_card_match_single_process(tmp_path, loss):
+@pytest.mark.parametrize('loss,knobs', [('mse', {}), ('wmrb', {}), ('wmrb', {'TMF_ITEM_SLICES': '3', 'TMF_USER_CHUNKS': '2'}),
+                                        ('mse', {'TMF_USER_CHUNKS': '3'})])
+def test_two_ranks_on_one_card_match_single_process(tmp_path, loss, knobs):
     """Two ranks, both on cuda:0, gloo group with host-staged collectives (tools/dp_rehearsal.py): the skewed
     user partition, the padded V, the reduce-scatter -> Adam-on-shard -> all-gather exchange and the loss
     all-reduce on the HIP engine reproduce the single-process fit.  The item gradient is summed in a different
@@ -608,7 +609,7 @@ def test_two_ranks_on_one_card_match_single_process(tmp_path, loss):
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), **knobs)  # knobs: sliced user pass / user-blocked lists on every rank
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tools', 'dp_rehearsal.py'), str(out), loss],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode() for p in procs]
