@@ -122,3 +122,25 @@ def wmrb_epoch(U, V, plan, n_items, n_samples, lr, want_grads=True):
     delta[plan.order] = plan.delta[:plan.nnz]
     mean = loss.value / npos.value if npos.value else float('nan')
     return Un, Vn, mean, dict(delta=delta, D=plan.D.copy(), gU=gU, gV=gV, loss_sum=loss.value, n_pos=npos.value)
+
+
+def wmrb_boundary_slack(U, V, plan, n_items, n_samples, tol_rel=1e-5):
+    """How far D / delta / gU / gV may move when hinge terms whose argument lies within ``tol_rel`` (the tolerance the
+    predictions are compared at) of the kink switch between active and inactive - see oracle_wmrb_boundary_slack in
+    sparse_ref.c.  -> dict(D, delta (input order), gU, gV, pairs)."""
+    L = lib()
+    L.oracle_wmrb_boundary_slack.restype = ctypes.c_int64
+    U = np.ascontiguousarray(U, dtype=np.float32)
+    V = np.ascontiguousarray(V, dtype=np.float32)
+    r = U.shape[1]
+    D = np.zeros((plan.m, plan.S), dtype=np.float32)
+    dl = np.zeros(max(plan.nnz, 1), dtype=np.float32)
+    gU, gV = np.zeros_like(U), np.zeros_like(V)
+    pairs = L.oracle_wmrb_boundary_slack(ctypes.c_int64(plan.m), ctypes.c_int64(plan.n), ctypes.c_int(r), ctypes.c_int64(plan.S),
+                                         ctypes.c_float(np.float32(n_items / n_samples)), ctypes.c_float(tol_rel), _p(plan.rowptr),
+                                         _p(plan.col), _p(plan.val), _p(plan.R), _p(U), _p(V), _p(D), _p(dl), _p(gU), _p(gV))
+    assert pairs >= 0
+    delta = np.empty(plan.nnz, dtype=np.float32)
+    delta[plan.order] = dl[:plan.nnz]
+    return dict(D=D, delta=delta, gU=gU, gV=gV, pairs=int(pairs))
+

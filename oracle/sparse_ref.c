@@ -202,3 +202,68 @@ int oracle_wmrb_epoch(int64_t m, int64_t n, int r, int64_t S, float c_ratio,
   *n_pos = positives;
   return 0;
 }
+
+/* How far the WMRB gradient may move when the predictions move by the parity tolerance.
+ *
+ * The hinge max(1 - p_k + sp[u,s], 0) has a kink at 0 (loss_graphs.py:83-84): a term whose argument x lies within the
+ * tolerance the predictions themselves are compared at (|x| <= tol_rel * (1 + |p_k| + |sp[u,s]|)) is active in one
+ * valid fp32 evaluation of the reference and inactive in another (different summation order of the r-wide dot
+ * products) - and switching it moves D[u,s] by w_k, delta_k by -w_k, gU[u] by w_k (V[R[u,s]] - V[j_k]) and the two
+ * item rows by +-w_k U[u].  This routine adds up those possible moves ("slack") per element, so that a test can state
+ * "equal to the closed form up to the activity of the boundary terms" instead of an unconditional 1e-5, which no
+ * fp32 implementation (the reference included) can meet once training has pushed hinge arguments onto the kink.
+ * Outputs (all optional but D_slack): D_slack [m,S], delta_slack [nnz], gU_slack [m,r], gV_slack [n,r]; returns the
+ * number of boundary (k, s) pairs, or -1. */
+int64_t oracle_wmrb_boundary_slack(int64_t m, int64_t n, int r, int64_t S, float c_ratio, float tol_rel,
+                                   const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
+                                   const float* U, const float* V,
+                                   float* D_slack, float* delta_slack, float* gU_slack, float* gV_slack) {
+  (void)n;
+  int64_t pairs = 0;
+#pragma omp parallel
+  {
+    float* sp = (float*)malloc((size_t)(S > 0 ? S : 1) * sizeof(float));
+#pragma omp for schedule(dynamic, 16) reduction(+ : pairs)
+    for (int64_t u = 0; u < m; ++u) {
+      const float* Uu = U + u * r;
+      const int32_t* Ru = R + u * S;
+      for (int64_t s = 0; s < S; ++s) sp[s] = dotf(Uu, V + (int64_t)Ru[s] * r, r);
+      for (int64_t k = rowptr[u]; k < rowptr[u + 1]; ++k) {
+        if (!(val[k] > 0.f)) continue;
+        const float* Vj = V + (int64_t)col[k] * r;
+        float p = dotf(Uu, Vj, r);
+        float base = 1.0f - p;
+        float hinge = 0.f;
+        int near = 0;
+        for (int64_t s = 0; s < S; ++s) {
+          float x = base + sp[s];
+          hinge += x > 0.f ? x : 0.f;
+          near += fabsf(x) <= tol_rel * (1.0f + fabsf(p) + fabsf(sp[s]));
+        }
+        if (!near) continue;
+        float w = c_ratio / (1.0f + c_ratio * hinge);
+        for (int64_t s = 0; s < S; ++s) {
+          float x = base + sp[s];
+          if (!(fabsf(x) <= tol_rel * (1.0f + fabsf(p) + fabsf(sp[s])))) continue;
+          pairs++;
+          const float* Vs = V + (int64_t)Ru[s] * r;
+          D_slack[u * S + s] += w;               /* row u belongs to this thread */
+          if (delta_slack) delta_slack[k] += w;
+          for (int c = 0; c < r; ++c) {
+            if (gU_slack) gU_slack[u * r + c] += w * fabsf(Vs[c] - Vj[c]);
+            if (gV_slack) {
+              float a = w * fabsf(Uu[c]);
+#pragma omp atomic
+              gV_slack[(int64_t)Ru[s] * r + c] += a;
+#pragma omp atomic
+              gV_slack[(int64_t)col[k] * r + c] += a;
+            }
+          }
+        }
+      }
+    }
+    free(sp);
+  }
+  return pairs;
+}
+

@@ -70,6 +70,32 @@ def wmrb_terms(U, V, indices, values, R, n_items, n_samples):
     return dict(pos=pos, p=p, M=M, loss=np.log(f(1.0) + M), w=w, cnt=cnt, delta=delta, D=D, sp=sp)
 
 
+def wmrb_slack(U, V, indices, values, R, n_items, n_samples, tol_rel=1e-5):
+    """How far D, delta (over the positives), gU and gV may move when the hinge terms whose argument x_ks lies within
+    the tolerance the predictions are compared at - |x_ks| <= tol_rel (1 + |p_k| + |sp[u,s]|) - switch between active
+    and inactive.  The hinge has a kink at 0 (loss_graphs.py:83-84): two valid fp32 evaluations of the reference
+    (different summation order of the dot products) disagree on exactly those terms, and one switch moves D[u,s] by
+    w_k, delta_k by w_k, gU[u] by w_k (V[R[u,s]] - V[j_k]) and the two item rows by w_k U[u].  Same quantity as
+    oracle_wmrb_boundary_slack in sparse_ref.c.  -> dict(D, delta, gU, gV, pairs)."""
+    t = wmrb_terms(U, V, indices, values, R, n_items, n_samples)
+    pos = t['pos']
+    u, j = indices[pos, 0], indices[pos, 1]
+    x = (1.0 - t['p'])[:, None] + t['sp'][u]
+    near = np.abs(x) <= tol_rel * (1.0 + np.abs(t['p'])[:, None] + np.abs(t['sp'][u]))
+    D = np.zeros(t['sp'].shape)
+    gU, gV = np.zeros(U.shape), np.zeros(V.shape)
+    kk, ss = np.nonzero(near)
+    w = t['w'][kk]
+    np.add.at(D, (u[kk], ss), w)
+    delta = np.zeros(len(pos))
+    np.add.at(delta, kk, w)
+    js = R[u[kk], ss]
+    np.add.at(gU, u[kk], w[:, None] * np.abs(V[js] - V[j[kk]]))
+    np.add.at(gV, js, w[:, None] * np.abs(U[u[kk]]))
+    np.add.at(gV, j[kk], w[:, None] * np.abs(U[u[kk]]))
+    return dict(D=D, delta=delta, gU=gU, gV=gV, pairs=int(len(kk)))
+
+
 def wmrb_epoch(U, V, indices, values, R, n_items, n_samples, lr):
     """Returns (U_new, V_new, mean_loss over positives, terms dict)."""
     t = wmrb_terms(U, V, indices, values, R, n_items, n_samples)

@@ -28,7 +28,15 @@ def rel_err(x, ref):
     return float(np.abs(x - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-def step_bounds(W0, g_ref, lr, rtol=1e-5):
+def close_with_slack(x, ref, slack=None, rtol=1e-5):
+    """max_i (|x_i - ref_i| - slack_i) <= rtol * max|ref|: norm-wise agreement except for what the boundary hinge terms
+    may legitimately move (oracle.sparse_ref.wmrb_slack / oracle_wmrb_boundary_slack)."""
+    x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
+    d = np.abs(x - ref) - (0.0 if slack is None else 1.0001 * np.asarray(slack, np.float64))
+    return float(d.max()) <= rtol * max(float(np.abs(ref).max()), 1e-30) if d.size else True
+
+
+def step_bounds(W0, g_ref, lr, rtol=1e-5, slack=None):
     """Interval every element of a factor table must fall in after ONE fresh-Adam step if the gradient the
     kernel summed is within ``rtol`` (norm-wise relative) of ``g_ref`` (fp64 closed form from the oracle).
 
@@ -48,12 +56,14 @@ def step_bounds(W0, g_ref, lr, rtol=1e-5):
     def step(gg):
         return W0 - (gg * omb1 * alpha) / (np.sqrt(gg * gg * omb2) + eps)
     tol = rtol * max(float(np.abs(g).max()) if g.size else 0.0, 1e-30)
-    slack = 1e-6 * np.maximum(np.abs(W0), lr) + 1e-12
-    return step(g + tol) - slack, step(g - tol) + slack
+    if slack is not None:  # what switching the boundary hinge terms may add to / take from every element
+        tol = tol + 1.0001 * np.asarray(slack, dtype=np.float64)
+    ulp = 1e-6 * np.maximum(np.abs(W0), lr) + 1e-12
+    return step(g + tol) - ulp, step(g - tol) + ulp
 
 
-def assert_step(W_new, W0, g_ref, lr, rtol=1e-5, what=''):
-    lo, hi = step_bounds(W0, g_ref, lr, rtol)
+def assert_step(W_new, W0, g_ref, lr, rtol=1e-5, what='', slack=None):
+    lo, hi = step_bounds(W0, g_ref, lr, rtol, slack)
     W = np.asarray(W_new, dtype=np.float64)
     bad = (W < lo) | (W > hi)
     if bad.any():

@@ -1,0 +1,132 @@
+"""One GPU's share of BASELINE config 5 (10M x 1M, r=256, bf16 factors / fp32 accumulate, 8 GPUs): 1.25M users x 1M
+items, ~1.25e8 interactions, S=1024, bf16 storage.  The oracle cannot run the epoch at this size, so parity goes through
+size-independent properties, as in test_gpu_fullsize.py:
+  * a user's D[u, :], delta_k, loss and new row depend on V and the user's own data only -> fp64 closed form
+    (oracle.sparse_ref) on the bf16-rounded tables for sampled users; the new row must lie in the step interval
+    rounded to bf16;
+  * an item's gradient is a weighted sum over its entry set, rebuilt here from R and the CSR arrays (not from the
+    engine's lists) and summed in fp64;
+  * loss = sum of the user partials; a second run gives the same bits.
+At 1M items the V table (512 MB) is beyond L2 and Infinity Cache: this is the configuration that really streams from HBM."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_err, step_bounds
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_np(x):
+    return torch.as_tensor(np.asarray(x, np.float32)).to(torch.bfloat16).to(torch.float32).numpy().astype(np.float64)
+
+
+def assert_step_bf16(W_new, W0, g_ref, lr, what=''):
+    lo, hi = step_bounds(W0, g_ref, lr)
+    W = np.asarray(W_new, np.float64)
+    bad = (W < _bf16_np(lo) - 1e-12) | (W > _bf16_np(hi) + 1e-12)
+    assert not bad.any(), f'{what}: {int(bad.sum())} of {bad.size} elements outside the bf16-rounded step interval'
+
+
+@pytest.fixture(scope='module')
+def c5():
+    sys.path.insert(0, ROOT)
+    import bench
+    from teamoflow_amd import _engine, _lib
+    from teamoflow_amd.mf.utils import random_sampler_device
+    _lib.get()
+    dev = torch.device('cuda', 0)
+    torch.cuda.empty_cache()
+    m, n, r, S, lr = 1_250_000, 1_000_000, 256, 1024, 0.1
+    idx, val = bench.gen_interactions(m, n, 125_000_000, 'zipf', 0, dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    U0 = (torch.randn(m, r, device=dev, generator=g) * 0.08).to(torch.bfloat16)
+    V0 = (torch.randn(n, r, device=dev, generator=g) * 0.08).to(torch.bfloat16)
+    ld = _lib.padded_ld(r)   # the plans are sized like MatrixFactorization._fit_sparse sizes them
+    plan = _engine.InteractionPlan(idx, val, m, n, csc=False)
+    R = random_sampler_device(n, m, S, seed=100, device=dev)
+    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n),
+                             item_slices=_engine.default_item_slices(n, ld), n_components=r)
+    assert wplan.user_chunks > 1 and wplan.n_slices > 1
+    st = _engine.TrainState(U0.float(), V0.float(), plan, r, wplan, dtype=torch.bfloat16)
+    assert torch.equal(st.U[:, :r], U0) and torch.equal(st.V[:, :r], V0)
+    adam = _engine.adam_constants(lr)
+    loss = torch.zeros(2, dtype=torch.float64, device=dev)
+    _engine.epoch_wmrb(st, adam, n / S, loss[0:1])
+    torch.cuda.synchronize()
+    out = dict(m=m, n=n, r=r, S=S, lr=lr, U0=U0, V0=V0, plan=plan, R=R, wplan=wplan, st=st, adam=adam, loss=loss,
+               engine=_engine, D_model=wplan.D_in_model_order())
+    yield out
+    out.clear()
+    torch.cuda.empty_cache()
+
+
+def check_user(c5, u):
+    from oracle import sparse_ref as S
+    st, plan, w, r = c5['st'], c5['plan'], c5['wplan'], c5['r']
+    b, e = int(plan.rowptr_u[u]), int(plan.rowptr_u[u + 1])
+    cols = plan.col_u[b:e].to(torch.int64)
+    Ru = c5['R'][u].to(torch.int64)
+    items, inv = torch.unique(torch.cat([cols, Ru]), return_inverse=True)
+    Vc = c5['V0'][items].float().cpu().numpy().astype(np.float64)
+    idx = np.stack([np.zeros(e - b, np.int64), inv[:e - b].cpu().numpy()], axis=1)
+    val = plan.val_u[b:e].cpu().numpy().astype(np.float64)
+    U64 = c5['U0'][u:u + 1].float().cpu().numpy().astype(np.float64)
+    Rc = inv[e - b:].cpu().numpy()[None]
+    t = S.wmrb_terms(U64, Vc, idx, val, Rc, c5['n'], c5['S'])
+    assert rel_err(c5['D_model'][u].cpu().numpy(), t['D'][0]) < 1e-5, u
+    assert rel_err(w.delta[b:e].cpu().numpy(), t['delta']) < 1e-5, u
+    assert abs(float(st.loss_part[u]) - t['loss'].sum()) <= 1e-5 * t['loss'].sum(), u
+    gU = (t['delta'][:, None] * Vc[idx[:, 1]]).sum(0) + t['D'][0] @ Vc[Rc[0]]
+    assert_step_bf16(st.U_nxt[u, :r].float().cpu().numpy()[None], U64, gU[None], c5['lr'], what=f'user {u}')
+
+
+def test_c5_shard_sampled_users(c5):
+    rng = np.random.default_rng(0)
+    deg = (c5['plan'].rowptr_u[1:] - c5['plan'].rowptr_u[:-1]).cpu().numpy()
+    for u in list(rng.integers(0, c5['m'], 16)) + [int(deg.argmax()), int(deg.argmin())]:
+        check_user(c5, int(u))
+
+
+def test_c5_shard_sampled_items_independent_entry_sets(c5):
+    st, plan, w, r, n = c5['st'], c5['plan'], c5['wplan'], c5['r'], c5['n']
+    C = w.user_chunks
+    lens = (w.rowptr_e[1:] - w.rowptr_e[:-1]).view(C, n).sum(0)
+    rng = np.random.default_rng(1)
+    items = [int(lens.argmax()), int(lens.argmin())] + list(rng.integers(0, n, 5))
+    for j in items:
+        us = (c5['R'] == j).nonzero()
+        g = (c5['D_model'][us[:, 0], us[:, 1]].to(torch.float64)[:, None] * st.U[us[:, 0], :r].to(torch.float64)).sum(0)
+        k = ((plan.col_u == j) & (plan.val_u > 0)).nonzero().flatten()
+        g = g + (w.delta[k].to(torch.float64)[:, None] * st.U[plan.user_ids[k], :r].to(torch.float64)).sum(0)
+        assert int(us.shape[0] + k.numel()) == int(lens[j]), j
+        assert_step_bf16(st.V_nxt[j, :r].float().cpu().numpy()[None], c5['V0'][j:j + 1].float().cpu().numpy(),
+                         g.cpu().numpy()[None], c5['lr'], what=f'item {j} ({int(lens[j])} entries)')
+        for u in us[rng.integers(0, len(us), 2), 0].tolist() if len(us) else []:
+            check_user(c5, u)
+
+
+def test_c5_shard_loss_and_reproducibility(c5):
+    st, eng = c5['st'], c5['engine']
+    total = float(c5['loss'][0])
+    assert abs(total - float(st.loss_part[:c5['m']].to(torch.float64).sum())) <= 1e-9 * total
+    U1, V1 = st.U_nxt.clone(), st.V_nxt.clone()
+    eng.epoch_wmrb(st, c5['adam'], c5['n'] / c5['S'], c5['loss'][1:2])
+    torch.cuda.synchronize()
+    assert float(c5['loss'][1]) == total
+    assert torch.equal(U1, st.U_nxt) and torch.equal(V1, st.V_nxt)
+
+
+def test_c5_shard_fused_topk_on_trained_tables(c5):
+    """predict at the config-5 shape: fused bf16 top-10 of 512 users over the 1M-item catalog equals the stable
+    top-10 of their materialised fp32 scores (by value: fp32 re-computation of bf16 products may differ in the last bit)."""
+    from teamoflow_amd import _ops
+    st, r = c5['st'], c5['r']
+    U, V = st.U_nxt[:512, :r], st.V_nxt[:, :r]
+    vals, idx = _ops.predict_topk(U, V, 10, return_values=True)
+    scores = U.float() @ V.float().T
+    want = torch.sort(scores, dim=1, descending=True, stable=True)[0][:, :10]
+    assert rel_err(vals.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    assert rel_err(torch.gather(scores, 1, idx.to(torch.int64)).cpu().numpy(), vals.cpu().numpy()) < 1e-5

@@ -1,0 +1,136 @@
+"""BASELINE configs at their stated sizes and the reference semantics the fixtures do not force:
+
+  * C3 (6040 x 3706, MovieLens-1M shape, r=64, WMRB, S = n // 2 = 1853 as the class default and S = n // 5 = 741 as
+    /root/reference/examples/benchmarking_ML.py:65 uses) against the C/OpenMP closed-form oracle: one step (loss, D,
+    delta, both tables in the step interval), a 20-epoch trajectory, teacher-forced steps from the oracle's later
+    state, recall@10.
+  * WMRB hinge exactly at zero: tf.maximum routes the gradient to its first argument when x >= y
+    (/root/reference/src/teamoflow/mf/loss_graphs.py:83-84), so a term with 1 - p_k + sp[u, s] == 0 counts as active.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_step, close_with_slack, rel_err
+from test_gpu_parity import check_one_step, fit_model, tm  # noqa: F401  (tm is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def c3_inputs(S_):
+    from oracle import datagen as G
+    m, n, r = 6040, 3706, 64
+    np.random.seed(0)
+    idx, val, shape, A = G.generate_random_interaction(m, n, density=1000209 / (0.9 * m * n))
+    R = np.stack([np.random.choice(n, S_, replace=False) for _ in range(m)]).astype(np.int32)  # utils.py:20
+    return idx, val, A, R, G.uniform_init(m, r, 1), G.uniform_init(n, r, 2)
+
+
+@pytest.mark.parametrize('S_', [1853, 741])
+def test_c3_full_size(tm, S_):  # noqa: F811
+    from oracle import dense_ref as D
+    from oracle import sparse_c as C
+    idx, val, A, R, U0, V0 = c3_inputs(S_)
+    m, n = A.shape
+    lr, epochs = 0.1, 20
+    assert len(val) > 990_000
+    plan = C.Plan(idx, val, m, n, R)
+    Uc, Vc, losses, first = U0, V0, [], None
+    for e in range(epochs):
+        Uc, Vc, mean, t = C.wmrb_epoch(Uc, Vc, plan, n, S_, lr, want_grads=(e == 0))
+        losses.append(mean)
+        if e == 0:
+            first = t
+    # one step from the initial tables: loss, D, delta, both tables.  "Equal" = within 1e-5 plus what the hinge terms
+    # sitting on the kink may move (C.wmrb_boundary_slack; none at the start, thousands of (k, s) pairs after training)
+    def check_step(model, Ub, Vb, mean, t, tag):
+        sl = C.wmrb_boundary_slack(Ub, Vb, plan, n, S_)
+        assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+        assert close_with_slack(model._state.wplan.D_in_model_order().cpu().numpy(), t['D'], sl['D']), tag
+        assert close_with_slack(model._state.wplan.delta.cpu().numpy(), t['delta'], sl['delta']), tag  # a switch moves cnt_k by 1, delta_k by w_k
+        assert_step(model.user_embedding.cpu().numpy(), Ub, t['gU'], lr, what=f'C3 U {tag}', slack=sl['gU'])
+        assert_step(model.item_embedding.cpu().numpy(), Vb, t['gV'], lr, what=f'C3 V {tag}', slack=sl['gV'])
+        return sl['pairs']
+    one = fit_model(tm, U0, V0, idx, val, (m, n), 1, lr, 'wmrb', R, n, S_)
+    assert check_step(one, U0, V0, losses[0], first, 'epoch 1') < 100
+    # 20 epochs: the near-sign Adam step amplifies fp32 reordering, so the tail is compared at trajectory tolerance
+    model = fit_model(tm, U0, V0, idx, val, (m, n), epochs, lr, 'wmrb', R, n, S_)
+    assert rel_err(model.loss_history_[:5], losses[:5]) < 1e-5
+    assert rel_err(model.loss_history_, losses) < 1e-3
+    assert model.loss_history_[-1] < model.loss_history_[0]
+    # teacher-forced step from the oracle's state after 20 epochs (hinges partly inactive by then)
+    Un, Vn, mean, t = C.wmrb_epoch(Uc, Vc, plan, n, S_, lr)
+    late = fit_model(tm, Uc, Vc, idx, val, (m, n), 1, lr, 'wmrb', R, n, S_)
+    pairs = check_step(late, Uc, Vc, mean, t, 'epoch 21')
+    # the criterion stays sharp: the boundary terms are a vanishing share of the hinge terms and of the rows
+    assert pairs < 2e-4 * len(val) * S_, pairs
+    # recall@10 of the engine-trained model against the oracle-trained one (BASELINE: within 1e-3)
+    got = float(model.recall_at_k(torch.tensor(A)).mean())
+    want = float(D.recall_at_k_dense(Uc, Vc, A, 10).mean())
+    assert abs(got - want) <= 1e-3, (got, want)
+    # ranking of the ORACLE's tables by the engine: bit-exact indices
+    model.user_embedding, model.item_embedding = torch.tensor(Uc).cuda(), torch.tensor(Vc).cuda()
+    assert np.array_equal(model.retrieve_user_recs(k=10), D.retrieve_user_recs_dense(Uc, Vc, k=10))
+
+
+def tie_problem():
+    """Dyadic factors: user u = [a_u, b_u, 0, 0], items 0..7 = [x_j, 0, 0, 0] (the positives), items 8..15 =
+    [0, y_j, 0, 0] (the negatives), so p_k = a_u x_j and sp[u, s] = b_u y_s exactly and 1 - p_k + sp hits 0 exactly
+    for the pairs on the diagonal (and for more once a_u, b_u scale them), with neighbours one ulp to either side."""
+    e23, e24 = 2.0 ** -23, 2.0 ** -24
+    x = np.array([2, 1.5, 1 + e23, 1, 0.5, 3, 1.25, 1 - e24], np.float32)
+    y = np.array([1, 0.5, e23, 0, -0.5, 2, 0.25, -e24], np.float32)
+    n, r = 16, 4
+    V = np.zeros((n, r), np.float32)
+    V[:8, 0], V[8:, 1] = x, y
+    ab = [(1, 1), (1, 1), (2, 2), (0.5, 0.5), (1, 2), (2, 1), (1, 0.5), (1, 1), (4, 1), (1, 1)]
+    m = len(ab)
+    U = np.zeros((m, r), np.float32)
+    U[:, 0], U[:, 1] = [p[0] for p in ab], [p[1] for p in ab]
+    rng = np.random.default_rng(0)
+    A = np.zeros((m, n), np.float32)
+    for u in range(m):
+        A[u, rng.choice(8, 6 if u else 8, replace=False)] = rng.integers(1, 6, 6 if u else 8)
+    A[7, 9] = 3        # a positive that is also one of the "negative" items
+    A[3, 2] = -2       # a non-positive stored value: contributes nothing
+    S_ = 9
+    R = np.stack([np.concatenate([rng.permutation(8)[:8] + 8, [rng.integers(0, 8)]]) for _ in range(m)])  # 8 negatives + 1 positive-type item
+    R[0] = np.concatenate([np.arange(8) + 8, [0]])
+    idx = np.argwhere(A != 0)
+    return U, V, idx, A[A != 0], A, R.astype(np.int64), S_
+
+
+@pytest.mark.parametrize('slices', [None, '3'])
+def test_wmrb_subgradient_at_exact_ties(tm, monkeypatch, slices):  # noqa: F811
+    from oracle import dense_ref as D
+    from oracle import sparse_ref as S
+    U0, V0, idx, val, A, R, S_ = tie_problem()
+    m, n = A.shape
+    if slices:
+        monkeypatch.setenv('TMF_ITEM_SLICES', slices)
+        monkeypatch.setenv('TMF_USER_CHUNKS', '2')
+    # the data really holds exact ties and one-ulp neighbours on both sides (fp32 arithmetic as the reference does it)
+    pos = val > 0
+    p = np.einsum('kc,kc->k', U0[idx[pos, 0]], V0[idx[pos, 1]])
+    sp = np.einsum('uc,usc->us', U0, V0[R])
+    xks = (np.float32(1) - p)[:, None] + sp[idx[pos, 0]]
+    assert (xks == 0).sum() >= 12 and ((xks > 0) & (xks < 1e-6)).sum() >= 2 and ((xks < 0) & (xks > -1e-6)).sum() >= 2
+    lr = 0.05
+    model, t = check_one_step(tm, U0, V0, idx, val, (m, n), lr, 'wmrb', R, n, S_, boundary_slack=False)
+    assert model._state.wplan.n_slices == (int(slices) if slices else 1)
+    # fp64 closed form with the `>=` rule
+    assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-6
+    assert rel_err(model._state.wplan.delta.cpu().numpy()[pos], t['delta']) < 1e-6
+    # every tie counted: cnt_k = -delta_k / w_k is an integer and equals the oracle's count of x >= 0
+    w = (n / S_) / (1.0 + t['M'])
+    cnt = -model._state.wplan.delta.cpu().numpy()[pos].astype(np.float64) / w
+    assert np.array_equal(np.rint(cnt), (xks >= 0).sum(1)) and np.abs(cnt - np.rint(cnt)).max() < 1e-4
+    # the dense autograd restatement (tf.maximum sub-gradient rule written out) agrees after one step
+    ref = D.fit_dense(U0, V0, idx, val, 'wmrb', 1, lr, random_ind=R, n_items=n, n_samples=S_)
+    assert abs(model.loss_history_[0] - ref['loss'][0]) <= 1e-5 * ref['loss'][0]
+    assert_step(ref['U'], U0, t['gU'], lr, what='dense oracle U')
+    assert_step(ref['V'], V0, t['gV'], lr, what='dense oracle V')
+    # flipping the rule to a strict `>` would change the answer visibly: this test can fail
+    strict = S.wmrb_terms(U0.astype(np.float64), V0.astype(np.float64), idx, val.astype(np.float64), R, n, S_)
+    act_strict = (((1.0 - strict['p'])[:, None] + strict['sp'][idx[pos, 0]]) > 0).sum(1)
+    assert (act_strict != (xks >= 0).sum(1)).any()

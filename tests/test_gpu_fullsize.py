@@ -44,29 +44,55 @@ def c4():
                 adam=adam, loss=loss, engine=_engine)
 
 
-def test_sampled_users_match_oracle(c4):
+def check_user_against_oracle(c4, u, V64=None):
+    """D[u, :], delta_k, loss and the new row of one user against the fp64 closed form (oracle.sparse_ref)."""
     from oracle import sparse_ref as S
-    rng = np.random.default_rng(0)
     st, plan, w = c4['st'], c4['plan'], c4['wplan']
+    b, e = int(plan.rowptr_u[u]), int(plan.rowptr_u[u + 1])
+    cols = plan.col_u[b:e].to(torch.int64)
+    Ru = c4['R'][u].to(torch.int64)
+    # only the rows this user touches (positives + negatives), remapped to a compact table
+    items, inv = torch.unique(torch.cat([cols, Ru]), return_inverse=True)
+    Vc = c4['V0'][items].cpu().numpy().astype(np.float64)
+    idx = np.stack([np.zeros(e - b, np.int64), inv[:e - b].cpu().numpy()], axis=1)
+    val = plan.val_u[b:e].cpu().numpy().astype(np.float64)
+    U64 = c4['U0'][u:u + 1].cpu().numpy().astype(np.float64)
+    Rc = inv[e - b:].cpu().numpy()[None]
+    t = S.wmrb_terms(U64, Vc, idx, val, Rc, c4['n'], c4['S'])
+    assert rel_err(c4['D_model'][u].cpu().numpy(), t['D'][0]) < 1e-5, u
+    pos = val > 0
+    assert rel_err(w.delta[b:e].cpu().numpy()[pos], t['delta']) < 1e-5, u
+    assert float(w.delta[b:e][~torch.as_tensor(pos, device=w.delta.device)].abs().sum()) == 0.0
+    assert abs(float(st.loss_part[u]) - t['loss'].sum()) <= 1e-5 * t['loss'].sum(), u
+    gU = (t['delta'][:, None] * Vc[idx[pos, 1]]).sum(0) + t['D'][0] @ Vc[Rc[0]]
+    assert_step(st.U_nxt[u, :c4['r']].cpu().numpy()[None], U64, gU[None], c4['lr'], what=f'user {u}')
+
+
+def test_sampled_users_match_oracle(c4):
+    rng = np.random.default_rng(0)
+    plan = c4['plan']
     deg = (plan.rowptr_u[1:] - plan.rowptr_u[:-1]).cpu().numpy()
     users = list(rng.integers(0, c4['m'], 24)) + [int(deg.argmax()), int(deg.argmin())]
-    V64 = c4['V0'].cpu().numpy().astype(np.float64)
-    rp = plan.rowptr_u.cpu().numpy()
     for u in users:
-        b, e = rp[u], rp[u + 1]
-        idx = np.stack([np.zeros(e - b, np.int64), plan.col_u[b:e].cpu().numpy().astype(np.int64)], axis=1)
-        val = plan.val_u[b:e].cpu().numpy().astype(np.float64)
-        U64 = c4['U0'][u:u + 1].cpu().numpy().astype(np.float64)
-        Ru = c4['R'][u:u + 1].cpu().numpy().astype(np.int64)
-        t = S.wmrb_terms(U64, V64, idx, val, Ru, c4['n'], c4['S'])
-        assert rel_err(c4['D_model'][u].cpu().numpy(), t['D'][0]) < 1e-5, u
-        assert rel_err(w.delta[b:e].cpu().numpy(), t['delta']) < 1e-5, u
-        assert abs(float(st.loss_part[u]) - t['loss'].sum()) <= 1e-5 * t['loss'].sum(), u
-        gU = (t['delta'][:, None] * V64[idx[:, 1]]).sum(0) + t['D'][0] @ V64[Ru[0]]
-        assert_step(st.U_nxt[u, :c4['r']].cpu().numpy()[None], U64, gU[None], c4['lr'], what=f'user {u}')
+        check_user_against_oracle(c4, int(u))
+
+
+def independent_item_gradient(j, R_model, D_model, plan, delta, U, r):
+    """fp64 gradient of item j from its entry set built WITHOUT the engine's entry lists: the (user, slot) pairs
+    with R[u, s] == j straight from the model-order negative table, the positives straight from the CSR arrays.
+    Returns (g [r] numpy fp64, number of entries)."""
+    us = (R_model == j).nonzero()                                 # [E_neg, 2] (user, slot)
+    w_neg = D_model[us[:, 0], us[:, 1]].to(torch.float64)
+    g = (w_neg[:, None] * U[us[:, 0], :r].to(torch.float64)).sum(0)
+    k = ((plan.col_u == j) & (plan.val_u > 0)).nonzero().flatten()  # CSR positions of the item's positives
+    g = g + (delta[k].to(torch.float64)[:, None] * U[plan.user_ids[k], :r].to(torch.float64)).sum(0)
+    return g.cpu().numpy(), int(us.shape[0] + k.numel())
 
 
 def test_sampled_items_match_fp64_resummation(c4):
+    """Item gradients against an entry set that does not come from WmrbPlan (ent_row / ent_w / rowptr_e are not read for
+    the sums): a (u, s) pair dropped, duplicated or put into the wrong user block by the plan shows up here.  The plan's
+    own list lengths must equal the independent entry counts."""
     st, plan, w = c4['st'], c4['plan'], c4['wplan']
     n, C = c4['n'], w.user_chunks
     rp = w.rowptr_e.cpu().numpy()
@@ -75,14 +101,14 @@ def test_sampled_items_match_fp64_resummation(c4):
     items = [int(lens.argmax()), int(lens.argmin())] + list(rng.integers(0, n, 6))
     assert lens.max() > 500_000  # the zipf head really is a ~1000-segment row
     for j in items:
-        g = np.zeros(c4['r'])
-        for blk in range(C):
-            b, e = int(rp[blk * n + j]), int(rp[blk * n + j + 1])
-            rows = w.ent_row[b:e].to(torch.int64)
-            wts = w.wbuf[w.ent_w[b:e]].to(torch.float64)
-            g += (wts[:, None] * st.U[rows, :c4['r']].to(torch.float64)).sum(0).cpu().numpy()
+        g, n_ent = independent_item_gradient(j, c4['R'], c4['D_model'], plan, w.delta, st.U, c4['r'])
+        assert n_ent == lens[j], (j, n_ent, lens[j])
         assert_step(st.V_nxt[j, :c4['r']].cpu().numpy()[None], c4['V0'][j:j + 1].cpu().numpy(), g[None], c4['lr'],
                     what=f'item {j} ({lens[j]} entries)')
+        # the weights used above are the engine's D / delta: pin a few of them to the oracle through their users
+        us = (c4['R'] == j).nonzero()
+        for u in us[rng.integers(0, len(us), 2), 0].tolist() if len(us) else []:
+            check_user_against_oracle(c4, u)
 
 
 def test_loss_is_sum_of_user_partials_and_runs_are_bit_identical(c4):

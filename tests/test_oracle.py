@@ -207,3 +207,24 @@ def test_c_oracle_random_shapes_and_thread_counts():
             assert_step(wV, V, ref[3]['gV'], 0.1)
         else:
             assert np.array_equal(wU, U) and np.array_equal(wV, V)
+
+
+def test_boundary_slack_c_equals_numpy_and_is_zero_away_from_the_kink(golden):
+    """oracle_wmrb_boundary_slack (C) == sparse_ref.wmrb_slack (NumPy) on a trained state; no boundary terms at the
+    start of training (every hinge argument is ~1) and only a small share of the terms later."""
+    from oracle import sparse_c as C
+    g = golden('wmrb_mixed')
+    n, S_ = int(g['n_items']), int(g['n_samples'])
+    idx, val, R = g['indices'], g['values'], g['R']
+    plan = C.Plan(idx, val, g['A'].shape[0], n, R)
+    assert C.wmrb_boundary_slack(g['U0'], g['V0'], plan, n, S_)['pairs'] == 0
+    for tol in (1e-5, 3e-2):   # 3e-2: enough boundary terms on this small problem to compare every output
+        U, V = g['U_10'], g['V_10']
+        a = C.wmrb_boundary_slack(U, V, plan, n, S_, tol_rel=tol)
+        b = S.wmrb_slack(U.astype(np.float64), V.astype(np.float64), idx, val.astype(np.float64), R, n, S_, tol_rel=tol)
+        pos = val > 0
+        assert abs(a['pairs'] - b['pairs']) <= max(2, 0.02 * b['pairs'])     # fp32 vs fp64 arguments right at the tolerance edge
+        if tol > 1e-3:
+            assert b['pairs'] > 20 and b['pairs'] < 0.2 * pos.sum() * S_
+            assert rel_err(a['D'], b['D']) < 0.1 and rel_err(a['gU'], b['gU']) < 0.1 and rel_err(a['gV'], b['gV']) < 0.1
+            assert rel_err(a['delta'][pos], b['delta']) < 0.1
