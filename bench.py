@@ -352,7 +352,7 @@ def main():
     if args.loss == 'wmrb':
         ub, ib = wmrb_bytes(m, n, S, plan.n_pos, r, sbytes)
         ums, ims = prof.mean_ms('wmrb_user_pass'), prof.mean_ms('wmrb_item_pass')
-        sliced = wplan.n_slices > 1
+        sliced = wplan.sliced
         # dominant single kernel: the fused user pass, or (sliced user pass = 4 kernels) the item gather-sum
         if not sliced and ums >= ims:
             kname, kbytes, kms = 'wmrb_user_pass', ub, ums

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TMF_VERSION 100 /* 0.1.0 */
+#define TMF_VERSION 200 /* 0.2.0 */
 
 #define TMF_OK 0
 #define TMF_E_INVALID (-1)   /* bad argument (null pointer, unsupported rank, size mismatch) */
@@ -78,14 +78,15 @@ typedef struct tmf_segments {
 
 /* Index preparation, once per fit() (there is no counterpart in the reference: it gathers from the dense
  * [m, n] score matrix with SparseTensor.indices, loss_graphs.py:47-50; these views are what lets the passes stream).
- *   tmf_csr_build: COO (indices [nnz, 2] int64 row-major pairs in any order, values [nnz]) -> CSR by user with the
- *     original order kept inside a user (stable): rowptr_u [n_users + 1], col_u / val_u / user_of [nnz].
+ *   tmf_csr_build: COO (indices [nnz, 2] int64 pairs in any order, values [nnz]) -> CSR by user, interactions of a user in
+ *     ascending item order (the row-major order tf.sparse.SparseTensor is specified in; duplicates keep their input
+ *     order): rowptr_u [n_users + 1], col_u / val_u / user_of [nnz].
  *   tmf_csc_perm:  stable order of the CSR entries by item: perm [nnz] (CSR positions), rowptr_i [n_items + 1].
  *   tmf_stable_order_i32: the building block - stable radix sort of int32 keys in [0, n_rows) with their positions,
  *     plus rowptr[r] = first sorted position with key >= r.  sorted_keys may be NULL.
  * workspace: caller-provided device scratch of at least the matching *_workspace_bytes(). */
 size_t tmf_csr_build_workspace_bytes(int64_t nnz);
-int tmf_csr_build(const int64_t* indices, const float* values, int64_t nnz, int32_t n_users,
+int tmf_csr_build(const int64_t* indices, const float* values, int64_t nnz, int32_t n_users, int32_t n_items,
                   int64_t* rowptr_u, int32_t* col_u, float* val_u, int32_t* user_of, void* workspace,
                   size_t workspace_bytes, void* stream);
 size_t tmf_stable_order_workspace_bytes(int64_t n);
@@ -93,6 +94,30 @@ int tmf_csc_perm(const int32_t* col_u, int64_t nnz, int32_t n_items, int64_t* ro
                  void* workspace, size_t workspace_bytes, void* stream);
 int tmf_stable_order_i32(const int32_t* keys, int64_t n, int64_t n_rows, int64_t* perm, int32_t* sorted_keys,
                          int64_t* rowptr, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Index structures of the sliced WMRB pass (built once per fit from the static negative table, utils.py:20):
+ *   tmf_sort_samples: R_sorted[u, :] = R[u, :] in ascending item order (the order of a user's negatives is immaterial
+ *     to the loss, loss_graphs.py:80-86).
+ *   tmf_slice_offsets: off[row][b] = first position of the row's ascending ids with id >= b * ceil(n_items / n_slices),
+ *     b = 0 .. n_slices (the last one = row length).  Rows have a fixed length `stride` (rowptr NULL: the negatives) or
+ *     are CSR rows (the interactions; offsets relative to rowptr[row]).
+ *   tmf_wmrb_entry_lists: the item-side lists of the WMRB gradient, split by user block (list row = user block * n_items
+ *     + item, blocks of ceil(n_users / user_chunks) users): every list holds the item's positives (ascending CSR
+ *     position) followed by the (user, sample) pairs whose negative is the item.  Entry ids: i < nnz = interaction i of
+ *     the CSR, nnz + u * S + s = negative s of user u (R_sorted order).  Outputs, E = nnz + n_users * S (< 2^31):
+ *       ent_row [E] user of every list entry; ent_id [E] (optional) entry id of every list entry; ent_pos [E] (optional)
+ *       position of every entry id in the lists (stored values <= 0 sit in a dummy list row behind all others);
+ *       rowptr_e [user_chunks * n_items + 2]. */
+size_t tmf_sort_samples_workspace_bytes(int32_t n_users, int32_t n_samples);
+int tmf_sort_samples(const int32_t* R, int32_t n_users, int32_t n_samples, int32_t n_items, int32_t* R_sorted,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int tmf_slice_offsets(const int32_t* ids, const int64_t* rowptr, int64_t stride, int32_t n_rows, int32_t n_items,
+                      int32_t n_slices, int32_t* off, void* stream);
+size_t tmf_wmrb_entry_lists_workspace_bytes(int64_t nnz, int32_t n_users, int32_t n_samples);
+int tmf_wmrb_entry_lists(const int32_t* user_of, const int32_t* col_u, const float* val_u, int64_t nnz,
+                         const int32_t* R_sorted, int32_t n_users, int32_t n_samples, int32_t n_items, int32_t user_chunks,
+                         int32_t* ent_row, int32_t* ent_id, int32_t* ent_pos, int64_t* rowptr_e, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* K1+K2 / K3: one side of an MSE epoch (loss_graphs.py:47-52 forward; tape.gradient
  * matrix_factorization.py:170-171; Adam :176) evaluated sparsely:
@@ -105,9 +130,10 @@ int tmf_mse_pass_f32(const tmf_segments* seg, const int32_t* other, const float*
                      float* loss_part, int n_components, int epi, tmf_adam adam, void* stream);
 
 /* Weighted row-gather-sum pass (item side of WMRB, matrix_factorization.py:170-171 through
- * loss_graphs.py:80-88):  g[i] = sum over entries e of row i of  wbuf[ent_w[e]] * T[ent_row[e]]
- * (entries with weight exactly 0 are skipped), then the epilogue writes X_out[i]. */
-int tmf_wsum_pass_f32(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w,
+ * loss_graphs.py:80-88):  g[i] = sum over entries e of row i of  w_e * T[ent_row[e]]  with w_e = wbuf[ent_w[e]], or
+ * w_e = wbuf[e] when ent_w is NULL (weights already stored in entry order, as tmf_wmrb_gradu3 leaves them); entries
+ * with weight exactly 0 are skipped; then the epilogue writes X_out[i]. */
+int tmf_wsum_pass_f32(const tmf_segments* seg, const int32_t* ent_row, const int32_t* ent_w,
                       const float* wbuf, const float* T, const float* X_old, float* X_out,
                       float* slab, int n_components, int epi, tmf_adam adam, void* stream);
 
@@ -117,8 +143,9 @@ int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int6
                          const float* slab, const float* X_old, float* X_out, int n_components,
                          int epi, tmf_adam adam, void* stream);
 
-/* K4+K5: user side of a WMRB epoch for users [0, n_users) (matrix_factorization.py:153-154 sampled
- * and serial scores, loss_graphs.py:74-88, gradient w.r.t. U, Adam :176).
+/* K4+K5: user side of a WMRB epoch for users [0, n_users) in ONE kernel (matrix_factorization.py:153-154 sampled
+ * and serial scores, loss_graphs.py:74-88, gradient w.r.t. U, Adam :176) - the form for catalogs whose V table the L2s
+ * hold and sample counts whose scores fit LDS (tmf_wmrb_user_pass_fits); everything else takes the sliced pass below.
  *   R [n_users, S] int32 static negative table (utils.py:20), c = n_items / n_samples (ctor ints);
  *   writes delta [nnz] (d loss / d p_k, 0 for non-positive entries), D [n_users, S],
  *   loss_part [n_users] (sum of log(1+M_k) over the user's positives), pos_part [n_users] (#positives),
@@ -126,53 +153,50 @@ int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int6
 int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                            const int32_t* R, int32_t n_users, int32_t S, float c,
                            const float* U_old, const float* V_old, float* U_out, float* delta,
-                           float* D, float* loss_part, float* pos_part, float* workspace,
+                           float* D, float* loss_part, float* pos_part,
                            int n_components, int epi, tmf_adam adam, void* stream);
-/* Bytes of `workspace` the call above needs: 0 while the per-user scores fit the 160 KB of LDS
- * (n_samples up to ~19K), otherwise n_users * round4(S) floats kept in global memory. */
-size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int n_components);
+/* 1 when the scores and D of one user (n_samples of them) fit the 160 KB of LDS next to the kernel's other buffers. */
+int tmf_wmrb_user_pass_fits(int32_t n_samples, int n_components);
 
-/* Sliced form of the same user pass for catalogs whose V table is larger than the L2s (speed only - the
- * results obey the same contract).  R_sorted [n_users, S] holds every user's negatives in ascending item
- * order; slice_off [n_users, n_slices + 1] int32 gives, per user, the first sample of every item slice
- * (slice_off[u][0] = 0, slice_off[u][n_slices] = S).  Kernels, called in this order on one stream:
- *   tmf_wmrb_scores2_*  sp[u, s] = <U[u], V[R_sorted[u, s]]>                       (slice-major grid)
- *   tmf_wmrb_hinge_*    delta, D (in R_sorted order), loss_part, gpos[u] = sum_k delta_k V[j_k]
- *   tmf_wmrb_gradu2_*   part[slice][u] = sum_{s in slice} D[u, s] V[R_sorted[u, s]]   (slice-major grid)
- *   tmf_wmrb_finish_*   U_out[u] = epilogue(gpos[u] + sum_slice part[slice][u])
- * sp [n_users, S], gpos [n_users, ld], part are caller-provided fp32 scratch. */
-
-/* Staged sliced pass (the default for catalogs larger than two slices) - tables are float (_f32) or bf16
- * (_bf16) rows, passed as void*; sp / gpos / part / D / delta stay fp32.
- * gradu2: per_slice_launches = 0 -> one launch, part is [n_slices * n_users, ld] and finish gets n_slices;
- *         per_slice_launches = 1 -> one launch per slice adding into a single [n_users, ld] layer (memory-light:
- *         finish is then called with n_slices = 1). */
-int tmf_wmrb_scores2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                          int32_t n_users, int32_t S, const void* U, const void* V, float* sp,
+/* Sliced form of the same user pass (speed only - same contract): the catalog is walked in n_slices slices of
+ * ~4 MB of V rows with a slice-major grid, so the row gathers of the resident workgroups hit the XCD L2s; it also has
+ * no limit on n_samples, and its hinge step costs O((S + P_u) log P_u) per user instead of O(P_u S).  The lists: */
+typedef struct tmf_slice_lists {
+    const int32_t* R_sorted;  /* [n_users, n_samples] negatives, ascending item id per user (tmf_sort_samples) */
+    const int32_t* slice_off; /* [n_users, n_slices + 1] (tmf_slice_offsets on R_sorted) */
+    const int64_t* rowptr;    /* [n_users + 1] CSR of the interactions, ascending item id inside a user (tmf_csr_build) */
+    const int32_t* col;       /* [nnz] */
+    const int32_t* pos_off;   /* [n_users, n_slices + 1] (tmf_slice_offsets on col with rowptr) */
+    int32_t n_users, n_samples, n_slices;
+} tmf_slice_lists;
+/* Kernels, called in this order on one stream (tables float (_f32) or bf16 (_bf16) rows as void*; sp / p / D / delta /
+ * part / w_ent are fp32):
+ *   tmf_wmrb_scores3_*  sp[u, s] = <U[u], V[R_sorted[u, s]]>, p[k] = <U[u_k], V[col[k]]>         (slice-major grid)
+ *   tmf_wmrb_hinge2     delta [nnz], D [n_users, n_samples] (R_sorted order), loss_part [n_users]; reads no table
+ *   tmf_wmrb_gradu3_*   part[slice][u] = sum_{s in slice} D[u, s] V[R_sorted[u, s]] + sum_{k in slice} delta_k V[col[k]]
+ *                       and, when ent_pos_* are given, w_ent[ent_pos_smp[u * S + s]] = D[u, s],
+ *                       w_ent[ent_pos_pos[k]] = delta_k (the weights of tmf_wsum_pass in entry order; negative
+ *                       positions are skipped)
+ *                       per_slice_launches = 0: one launch, part is [n_slices * n_users, ld], finish gets n_slices;
+ *                       per_slice_launches = 1: one launch per slice adding into ONE [n_users, ld] layer (memory-light;
+ *                       finish is then called with n_slices = 1)
+ *   tmf_wmrb_finish_*   U_out[u] = epilogue(sum_slice part[slice][u]) */
+int tmf_wmrb_scores3_f32(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,
+                         int n_components, void* stream);
+int tmf_wmrb_scores3_bf16(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,
                           int n_components, void* stream);
-int tmf_wmrb_hinge_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
-                        int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old,
-                        float* gpos, float* delta, float* D, float* loss_part, int n_components,
-                        void* stream);
-int tmf_wmrb_gradu2_f32(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                         int32_t n_users, int32_t S, const float* D, const void* V, float* part,
-                         int per_slice_launches, int n_components, void* stream);
-int tmf_wmrb_finish_f32(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
-                         const void* U_old, void* U_out, int n_components, int epi, tmf_adam adam,
-                         void* stream);
-int tmf_wmrb_scores2_bf16(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                          int32_t n_users, int32_t S, const void* U, const void* V, float* sp,
-                          int n_components, void* stream);
-int tmf_wmrb_hinge_bf16(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,
-                        int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old,
-                        float* gpos, float* delta, float* D, float* loss_part, int n_components,
-                        void* stream);
-int tmf_wmrb_gradu2_bf16(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,
-                         int32_t n_users, int32_t S, const float* D, const void* V, float* part,
-                         int per_slice_launches, int n_components, void* stream);
-int tmf_wmrb_finish_bf16(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,
-                         const void* U_old, void* U_out, int n_components, int epi, tmf_adam adam,
-                         void* stream);
+int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
+                    int32_t n_samples, float c, float* delta, float* D, float* loss_part, void* stream);
+int tmf_wmrb_gradu3_f32(const tmf_slice_lists* lists, const float* D, const float* delta, const int32_t* ent_pos_smp,
+                        const int32_t* ent_pos_pos, float* w_ent, const void* V, float* part, int per_slice_launches,
+                        int n_components, void* stream);
+int tmf_wmrb_gradu3_bf16(const tmf_slice_lists* lists, const float* D, const float* delta, const int32_t* ent_pos_smp,
+                         const int32_t* ent_pos_pos, float* w_ent, const void* V, float* part, int per_slice_launches,
+                         int n_components, void* stream);
+int tmf_wmrb_finish_f32(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,
+                        int n_components, int epi, tmf_adam adam, void* stream);
+int tmf_wmrb_finish_bf16(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,
+                         int n_components, int epi, tmf_adam adam, void* stream);
 
 /* K6 standalone: W[rows] = fresh-Adam(W[rows], G[rows]) in place over n_rows x ld floats. */
 int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,
@@ -206,7 +230,7 @@ int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx,
 int tmf_mse_pass_bf16(const tmf_segments* seg, const int32_t* other, const float* val,
                       const void* X_old, const void* Y_old, void* X_out, float* slab,
                       float* loss_part, int n_components, int epi, tmf_adam adam, void* stream);
-int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_row, const int64_t* ent_w,
+int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_row, const int32_t* ent_w,
                        const float* wbuf, const void* T, const void* X_old, void* X_out,
                        float* slab, int n_components, int epi, tmf_adam adam, void* stream);
 int tmf_combine_rows_bf16(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
@@ -215,7 +239,7 @@ int tmf_combine_rows_bf16(const int32_t* long_rows, const int64_t* slab_beg, int
 int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col, const float* val,
                             const int32_t* R, int32_t n_users, int32_t S, float c,
                             const void* U_old, const void* V_old, void* U_out, float* delta,
-                            float* D, float* loss_part, float* pos_part, float* workspace,
+                            float* D, float* loss_part, float* pos_part,
                             int n_components, int epi, tmf_adam adam, void* stream);
 int tmf_adam_fresh_rows_bf16(void* W, const float* G, int64_t n_rows, int n_components,
                              tmf_adam adam, void* stream);

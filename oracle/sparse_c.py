@@ -124,7 +124,7 @@ def wmrb_epoch(U, V, plan, n_items, n_samples, lr, want_grads=True):
     return Un, Vn, mean, dict(delta=delta, D=plan.D.copy(), gU=gU, gV=gV, loss_sum=loss.value, n_pos=npos.value)
 
 
-def wmrb_boundary_slack(U, V, plan, n_items, n_samples, tol_rel=1e-5):
+def wmrb_boundary_slack(U, V, plan, n_items, n_samples, tol_rel=None):
     """How far D / delta / gU / gV may move when hinge terms whose argument lies within ``tol_rel`` (the tolerance the
     predictions are compared at) of the kink switch between active and inactive - see oracle_wmrb_boundary_slack in
     sparse_ref.c.  -> dict(D, delta (input order), gU, gV, pairs)."""
@@ -133,6 +133,8 @@ def wmrb_boundary_slack(U, V, plan, n_items, n_samples, tol_rel=1e-5):
     U = np.ascontiguousarray(U, dtype=np.float32)
     V = np.ascontiguousarray(V, dtype=np.float32)
     r = U.shape[1]
+    if tol_rel is None:
+        tol_rel = max(1e-5, 2 * r * 2.0 ** -24)
     D = np.zeros((plan.m, plan.S), dtype=np.float32)
     dl = np.zeros(max(plan.nnz, 1), dtype=np.float32)
     gU, gV = np.zeros_like(U), np.zeros_like(V)

@@ -15,8 +15,8 @@
  * This file is the multi-threaded CPU baseline SURVEY.md 8(d) asks for at C4/C5 ("sparse CPU restatement,
  * not the reference formulation") and a third, independently written oracle for the tests.
  *
- * Arithmetic: scores, hinge terms and the Adam step in fp32 (the reference's dtype); row sums of the
- * gradients accumulate in fp64 and are rounded once (a CPU can afford it, and it puts this oracle
+ * Arithmetic: scores, hinge terms and the Adam step in fp32 (the reference's dtype); the sum of a positive's hinge
+ * terms and the row sums of the gradients accumulate in fp64 and are rounded once (a CPU can afford it, and it puts this oracle
  * nearer the exact closed form than any fp32 summation order).
  * Build: gcc -O3 -fopenmp -ffp-contract=off -mavx2 -shared -fPIC (oracle/Makefile).
  */
@@ -44,6 +44,13 @@ static inline float dotf(const float* x, const float* y, int r) {
   float acc = 0.f;
 #pragma omp simd reduction(+ : acc)
   for (int c = 0; c < r; ++c) acc += x[c] * y[c];
+  return acc;
+}
+
+static inline float absdotf(const float* x, const float* y, int r) {
+  float acc = 0.f;
+#pragma omp simd reduction(+ : acc)
+  for (int c = 0; c < r; ++c) acc += fabsf(x[c] * y[c]);
   return acc;
 }
 
@@ -152,15 +159,15 @@ int oracle_wmrb_epoch(int64_t m, int64_t n, int r, int64_t S, float c_ratio,
         if (!(val[k] > 0.f)) continue;                 /* loss_graphs.py:76-77: positives only */
         const float* Vj = V + (int64_t)col[k] * r;
         float base = 1.0f - dotf(Uu, Vj, r);
-        float hinge = 0.f;
+        double hinge = 0.0;                            /* fp32 terms as the reference forms them, summed in fp64 */
         int cnt = 0;
 #pragma omp simd reduction(+ : hinge, cnt)
         for (int64_t s = 0; s < S; ++s) {
           float x = base + sp[s];
-          hinge += x > 0.f ? x : 0.f;
+          hinge += x > 0.f ? (double)x : 0.0;
           cnt += x >= 0.f;                             /* tf.maximum: gradient to x when x >= 0 */
         }
-        float M = c_ratio * hinge;
+        float M = c_ratio * (float)hinge;
         float w = c_ratio / (1.0f + M);
         total += (double)logf(1.0f + M);
         positives++;
@@ -206,9 +213,11 @@ int oracle_wmrb_epoch(int64_t m, int64_t n, int r, int64_t S, float c_ratio,
 /* How far the WMRB gradient may move when the predictions move by the parity tolerance.
  *
  * The hinge max(1 - p_k + sp[u,s], 0) has a kink at 0 (loss_graphs.py:83-84): a term whose argument x lies within the
- * tolerance the predictions themselves are compared at (|x| <= tol_rel * (1 + |p_k| + |sp[u,s]|)) is active in one
- * valid fp32 evaluation of the reference and inactive in another (different summation order of the r-wide dot
- * products) - and switching it moves D[u,s] by w_k, delta_k by -w_k, gU[u] by w_k (V[R[u,s]] - V[j_k]) and the two
+ * tolerance the predictions themselves are compared at is active in one valid fp32 evaluation of the reference and
+ * inactive in another (different summation order of the r-wide dot products):
+ *     |x| <= tol_rel * (1 + sum_c |U[u,c] V[j_k,c]| + sum_c |U[u,c] V[R[u,s],c]|)
+ * (an fp32 dot product of length r is only determined up to r * 2^-24 times the sum of the magnitudes of its terms, so
+ * callers pass tol_rel = max(1e-5, 2 r 2^-24)).  Switching such a term moves D[u,s] by w_k, delta_k by -w_k, gU[u] by w_k (V[R[u,s]] - V[j_k]) and the two
  * item rows by +-w_k U[u].  This routine adds up those possible moves ("slack") per element, so that a test can state
  * "equal to the closed form up to the activity of the boundary terms" instead of an unconditional 1e-5, which no
  * fp32 implementation (the reference included) can meet once training has pushed hinge arguments onto the kink.
@@ -223,28 +232,33 @@ int64_t oracle_wmrb_boundary_slack(int64_t m, int64_t n, int r, int64_t S, float
 #pragma omp parallel
   {
     float* sp = (float*)malloc((size_t)(S > 0 ? S : 1) * sizeof(float));
+    float* asp = (float*)malloc((size_t)(S > 0 ? S : 1) * sizeof(float));
 #pragma omp for schedule(dynamic, 16) reduction(+ : pairs)
     for (int64_t u = 0; u < m; ++u) {
       const float* Uu = U + u * r;
       const int32_t* Ru = R + u * S;
-      for (int64_t s = 0; s < S; ++s) sp[s] = dotf(Uu, V + (int64_t)Ru[s] * r, r);
+      for (int64_t s = 0; s < S; ++s) {
+        sp[s] = dotf(Uu, V + (int64_t)Ru[s] * r, r);
+        asp[s] = absdotf(Uu, V + (int64_t)Ru[s] * r, r);
+      }
       for (int64_t k = rowptr[u]; k < rowptr[u + 1]; ++k) {
         if (!(val[k] > 0.f)) continue;
         const float* Vj = V + (int64_t)col[k] * r;
         float p = dotf(Uu, Vj, r);
+        float ap = 1.0f + absdotf(Uu, Vj, r);
         float base = 1.0f - p;
         float hinge = 0.f;
         int near = 0;
         for (int64_t s = 0; s < S; ++s) {
           float x = base + sp[s];
           hinge += x > 0.f ? x : 0.f;
-          near += fabsf(x) <= tol_rel * (1.0f + fabsf(p) + fabsf(sp[s]));
+          near += fabsf(x) <= tol_rel * (ap + asp[s]);
         }
         if (!near) continue;
         float w = c_ratio / (1.0f + c_ratio * hinge);
         for (int64_t s = 0; s < S; ++s) {
           float x = base + sp[s];
-          if (!(fabsf(x) <= tol_rel * (1.0f + fabsf(p) + fabsf(sp[s])))) continue;
+          if (!(fabsf(x) <= tol_rel * (ap + asp[s]))) continue;
           pairs++;
           const float* Vs = V + (int64_t)Ru[s] * r;
           D_slack[u * S + s] += w;               /* row u belongs to this thread */
@@ -263,6 +277,7 @@ int64_t oracle_wmrb_boundary_slack(int64_t m, int64_t n, int r, int64_t S, float
       }
     }
     free(sp);
+    free(asp);
   }
   return pairs;
 }

@@ -70,18 +70,23 @@ def wmrb_terms(U, V, indices, values, R, n_items, n_samples):
     return dict(pos=pos, p=p, M=M, loss=np.log(f(1.0) + M), w=w, cnt=cnt, delta=delta, D=D, sp=sp)
 
 
-def wmrb_slack(U, V, indices, values, R, n_items, n_samples, tol_rel=1e-5):
+def wmrb_slack(U, V, indices, values, R, n_items, n_samples, tol_rel=None):
     """How far D, delta (over the positives), gU and gV may move when the hinge terms whose argument x_ks lies within
-    the tolerance the predictions are compared at - |x_ks| <= tol_rel (1 + |p_k| + |sp[u,s]|) - switch between active
-    and inactive.  The hinge has a kink at 0 (loss_graphs.py:83-84): two valid fp32 evaluations of the reference
+    the tolerance the predictions are compared at - |x_ks| <= tol_rel (1 + sum_c |U V[j_k]| + sum_c |U V[R[u,s]]|),
+    tol_rel = max(1e-5, 2 r 2^-24): an fp32 dot product is only determined up to r 2^-24 times the sum of the magnitudes
+    of its terms - switch between active and inactive.  The hinge has a kink at 0 (loss_graphs.py:83-84): two valid fp32 evaluations of the reference
     (different summation order of the dot products) disagree on exactly those terms, and one switch moves D[u,s] by
     w_k, delta_k by w_k, gU[u] by w_k (V[R[u,s]] - V[j_k]) and the two item rows by w_k U[u].  Same quantity as
     oracle_wmrb_boundary_slack in sparse_ref.c.  -> dict(D, delta, gU, gV, pairs)."""
     t = wmrb_terms(U, V, indices, values, R, n_items, n_samples)
     pos = t['pos']
     u, j = indices[pos, 0], indices[pos, 1]
+    if tol_rel is None:
+        tol_rel = max(1e-5, 2 * U.shape[1] * 2.0 ** -24)
     x = (1.0 - t['p'])[:, None] + t['sp'][u]
-    near = np.abs(x) <= tol_rel * (1.0 + np.abs(t['p'])[:, None] + np.abs(t['sp'][u]))
+    ap = np.einsum('kc,kc->k', np.abs(U[u]), np.abs(V[j]))
+    asp = np.einsum('uc,usc->us', np.abs(U), np.abs(V[R]))
+    near = np.abs(x) <= tol_rel * (1.0 + ap[:, None] + asp[u])
     D = np.zeros(t['sp'].shape)
     gU, gV = np.zeros(U.shape), np.zeros(V.shape)
     kk, ss = np.nonzero(near)

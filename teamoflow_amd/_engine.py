@@ -93,7 +93,9 @@ class SegmentTable:
 
 
 class InteractionPlan:
-    """CSR-by-user and CSC-by-item views of the interactions (values duplicated in both orders)."""
+    """CSR-by-user and CSC-by-item views of the interactions (values duplicated in both orders).  Inside a user the
+    interactions are in ascending item order - the row-major order tf.sparse.SparseTensor is specified in - whatever
+    order the caller's COO list has (duplicates keep their input order)."""
 
     def __init__(self, indices, values, n_users, n_items, chunk=DEFAULT_CHUNK, user_chunks=1, csc=True):
         dev = indices.device
@@ -105,26 +107,27 @@ class InteractionPlan:
         values = values.to(torch.float32).contiguous()
         self.nnz, self.n_users, self.n_items = nnz, n_users, n_items
         if indices.is_cuda and nnz < 2 ** 31:
-            # native: stable sort by user, gather columns / values, row pointers (tmf_csr_build)
+            # native: one stable sort on user * n_items + item, row pointers, column / value gather (tmf_csr_build)
             lib = _lib.get()
             idx64 = indices.to(torch.int64).contiguous()
             self.rowptr_u = torch.empty(n_users + 1, dtype=torch.int64, device=dev)
             self.col_u = torch.empty(nnz, dtype=torch.int32, device=dev)
             self.val_u = torch.empty(nnz, dtype=torch.float32, device=dev)
-            user_of = torch.empty(nnz, dtype=torch.int32, device=dev)
+            self.user_of = torch.empty(nnz, dtype=torch.int32, device=dev)
             ws = torch.empty(lib.tmf_csr_build_workspace_bytes(nnz), dtype=torch.uint8, device=dev)
-            _lib.check(lib.tmf_csr_build(_lib.ptr(idx64), _lib.ptr(values), nnz, n_users, _lib.ptr(self.rowptr_u),
-                                         _lib.ptr(self.col_u), _lib.ptr(self.val_u), _lib.ptr(user_of), _lib.ptr(ws),
+            _lib.check(lib.tmf_csr_build(_lib.ptr(idx64), _lib.ptr(values), nnz, n_users, n_items, _lib.ptr(self.rowptr_u),
+                                         _lib.ptr(self.col_u), _lib.ptr(self.val_u), _lib.ptr(self.user_of), _lib.ptr(ws),
                                          ws.numel(), _lib.stream_ptr()), lib)
-            u, j, values = user_of.to(torch.int64), self.col_u.to(torch.int64), self.val_u
             del ws, idx64
         else:
-            if nnz > 1 and not bool((u[1:] >= u[:-1]).all()):
-                perm = torch.sort(u, stable=True)[1]
+            key = u.to(torch.int64) * n_items + j.to(torch.int64)
+            if nnz > 1 and not bool((key[1:] >= key[:-1]).all()):
+                perm = torch.sort(key, stable=True)[1]
                 u, j, values = u[perm], j[perm], values[perm]
             self.rowptr_u = _excl_cumsum(torch.bincount(u, minlength=n_users))
             self.col_u = j.to(torch.int32)
             self.val_u = values.contiguous()
+            self.user_of = u.to(torch.int32)
         self.seg_u = SegmentTable(self.rowptr_u, chunk)
         # CSC by item (only the MSE item pass reads it); with user_chunks = C > 1 by (user block, item), blocks
         # outermost, so that the U rows gathered at any time come from one cache-sized block of users
@@ -134,19 +137,23 @@ class InteractionPlan:
         if csc:
             if C > 1:
                 upc = -(-n_users // C)
-                key = (u // upc) * n_items + j
+                key = (self.user_of.to(torch.int64) // upc) * n_items + self.col_u.to(torch.int64)
             else:
-                key = j
+                key = self.col_u
             perm_c, self.rowptr_i = stable_order(key, C * n_items)
-            self.row_i = u[perm_c].to(torch.int32)
-            self.val_i = values[perm_c].contiguous()
+            self.row_i = self.user_of[perm_c].contiguous()
+            self.val_i = self.val_u[perm_c].contiguous()
             if C > 1:
                 out_row = torch.arange(C * n_items, device=dev) % n_items
                 self.seg_i = SegmentTable(self.rowptr_i, chunk, out_row=out_row, n_out=n_items, row_mod=n_items)
             else:
                 self.seg_i = SegmentTable(self.rowptr_i, chunk)
-        self.n_pos = int((values > 0).sum())
-        self.user_ids = u  # int64, CSR order (kept for the WMRB entry lists)
+        self.n_pos = int((self.val_u > 0).sum())
+
+    @property
+    def user_ids(self):
+        """int64 user of every CSR entry (tests, multi-GPU bookkeeping)."""
+        return self.user_of.to(torch.int64)
 
 
 def _slab_budget():
@@ -200,75 +207,125 @@ def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20):
     return int(min(-(-n_items * ld * 4 // target_bytes), 64))
 
 
-class WmrbPlan:
-    """Per-item entry lists of the WMRB item-side gradient:
-    positives of the item (weight delta_k) followed by the (user, sample-slot) pairs whose static
-    negative is the item (weight D[u, s]); weights live in one buffer wbuf = [delta | D].
+def fused_user_pass_fits(n_samples, n_components):
+    """The one-kernel user pass keeps a user's scores and D in LDS; above ~13K negatives they do not fit and the sliced
+    pass (no such limit) takes over whatever the catalog size."""
+    return bool(_lib.load_library().tmf_wmrb_user_pass_fits(int(n_samples), min(int(n_components), 1024)))
 
-    With user_chunks = C > 1 the lists are additionally split by user block (list row = block * n_items +
-    item, blocks outermost): the waves running at any moment then gather U rows of ONE block of users,
-    which fits the Infinity Cache, instead of rows scattered over the whole table."""
+
+class WmrbPlan:
+    """Index structures of a WMRB fit, built once from the interactions and the static negative table.
+
+    Item side: per-(user block, item) entry lists - the item's positives followed by the (user, sample) pairs whose
+    negative is the item; list row = block * n_items + item, blocks of ceil(n_users / user_chunks) users outermost, so
+    the waves running at any moment gather U rows of ONE cache-sized block of users.  Entry ids: k < nnz = interaction k
+    of the CSR, nnz + u * S + s = negative s of user u; ``ent_row[e]`` = user of list entry e.
+    Weights: ``wbuf = [delta (nnz) | D (m * S)]`` indexed by entry id.  The fused user pass writes it and the item pass
+    gathers through ``ent_w`` (entry id of every list entry); the sliced user pass (``sliced``) additionally stores
+    every weight at its list position (``ent_pos``: entry id -> list position, ``w_ent``), which the item pass streams.
+    Sliced pass: ``R`` holds every user's negatives in ascending item order, ``slice_off`` / ``pos_off`` the first
+    negative / interaction of every item slice."""
 
     def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128):
         dev = R.device
         m, S = R.shape
-        self.n_slices = max(1, int(item_slices))
-        if self.n_slices > 1 and _lib.load_library().tmf_wmrb_user_workspace_bytes(1, S, max(int(n_components), 512)) > 0:  # conservative ld
-            # scores + D of one user do not fit LDS (n_samples beyond ~13K): only the fused pass has the
-            # global-workspace variant, so the catalog is not sliced however large it is
-            self.n_slices = 1
-        self.sample_perm = None
-        if self.n_slices > 1:
-            # every user's negatives in ascending item order (the order of s is immaterial to the loss);
-            # D is then produced in this order too - D_in_model_order() maps it back
-            R64, self.sample_perm = torch.sort(R.to(torch.int64), dim=1, stable=True)
-            R = R64.to(torch.int32).contiguous()
-            width = -(-plan.n_items // self.n_slices)
-            bnd = torch.arange(self.n_slices + 1, device=dev, dtype=torch.int64) * width
-            self.slice_off = torch.searchsorted(R64, bnd[None, :].expand(m, -1).contiguous()).to(torch.int32).contiguous()
-            self.slice_off[:, -1] = S
-            del R64
         nnz, n = plan.nnz, plan.n_items
-        C = max(1, int(user_chunks))
-        upc = -(-m // C)  # users per block
-        pos_k = torch.nonzero(plan.val_u > 0).flatten()  # CSR positions of the positives
-        P = pos_k.numel()
-        pos_u = plan.user_ids[pos_k]
-        keys_pos = plan.col_u[pos_k].to(torch.int64)
-        keys_smp = R.reshape(-1).to(torch.int64)
-        if C > 1:
-            keys_pos = keys_pos + (pos_u // upc) * n
-            keys_smp = keys_smp + (torch.arange(m, device=dev) // upc).repeat_interleave(S) * n
-        keys = torch.cat([keys_pos, keys_smp])
-        del keys_pos, keys_smp
-        order, self.rowptr_e = stable_order(keys, C * n)
-        del keys
-        is_pos = order < P
-        e = order - P  # sample entry id u * S + s (negative for positives, unused there)
-        if P:
-            pk = pos_k[torch.clamp(order, max=P - 1)]
-            ent_row = torch.where(is_pos, plan.user_ids[pk], e // S)
-            ent_w = torch.where(is_pos, pk, nnz + e)
+        self.S, self.n_slices = S, max(1, int(item_slices))
+        self.sliced = self.n_slices > 1 or not fused_user_pass_fits(S, n_components)
+        C = self.user_chunks = max(1, int(user_chunks))
+        E = nnz + m * S
+        if E >= 2 ** 31:
+            raise ValueError(f'interactions + n_users * n_samples = {E} >= 2^31 on one GPU: split the users over more GPUs')
+        self.R_model = R  # the caller's table (model order): only D_in_model_order() reads it
+        native = R.is_cuda
+        lib = _lib.get() if native else None
+        i32 = ctypes.c_int32
+        self.slice_off = self.pos_off = None
+        if self.sliced:
+            # every user's negatives in ascending item order (the order of s is immaterial to the loss); D is
+            # produced in this order - D_in_model_order() maps it back
+            ns = self.n_slices
+            if native:
+                Rs = torch.empty_like(R)
+                ws = torch.empty(lib.tmf_sort_samples_workspace_bytes(m, S), dtype=torch.uint8, device=dev)
+                _lib.check(lib.tmf_sort_samples(_lib.ptr(R), i32(m), i32(S), i32(n), _lib.ptr(Rs), _lib.ptr(ws), ws.numel(),
+                                                _lib.stream_ptr()), lib)
+                del ws
+                self.slice_off = torch.empty(m, ns + 1, dtype=torch.int32, device=dev)
+                self.pos_off = torch.empty(m, ns + 1, dtype=torch.int32, device=dev)
+                _lib.check(lib.tmf_slice_offsets(_lib.ptr(Rs), None, S, i32(m), i32(n), i32(ns), _lib.ptr(self.slice_off),
+                                                 _lib.stream_ptr()), lib)
+                _lib.check(lib.tmf_slice_offsets(_lib.ptr(plan.col_u), _lib.ptr(plan.rowptr_u), 0, i32(m), i32(n), i32(ns),
+                                                 _lib.ptr(self.pos_off), _lib.stream_ptr()), lib)
+            else:
+                Rs = torch.sort(R.to(torch.int64), dim=1, stable=True)[0].to(torch.int32).contiguous()
+                width = -(-n // ns)
+                bnd = torch.arange(ns + 1, dtype=torch.int64) * width
+                self.slice_off = torch.searchsorted(Rs.to(torch.int64), bnd[None, :].expand(m, -1).contiguous()).to(torch.int32)
+                self.slice_off[:, -1] = S
+                key = plan.user_of.to(torch.int64) * (ns * width + 1) + plan.col_u.to(torch.int64)  # ascending (CSR order)
+                q = torch.arange(m, dtype=torch.int64)[:, None] * (ns * width + 1) + bnd[None, :]
+                self.pos_off = (torch.searchsorted(key, q.reshape(-1)).reshape(m, ns + 1) - plan.rowptr_u[:-1, None]).to(torch.int32)
+                self.pos_off[:, -1] = (plan.rowptr_u[1:] - plan.rowptr_u[:-1]).to(torch.int32)
+            R = Rs
+        self.R = R.contiguous()
+        # ---- item-side entry lists ----
+        self.ent_row = torch.empty(E, dtype=torch.int32, device=dev)
+        self.ent_w = self.ent_pos = None
+        rowptr = torch.empty(C * n + 2, dtype=torch.int64, device=dev)
+        if native:
+            ent_id = None if self.sliced else torch.empty(E, dtype=torch.int32, device=dev)
+            ent_pos = torch.empty(E, dtype=torch.int32, device=dev) if self.sliced else None
+            ws = torch.empty(lib.tmf_wmrb_entry_lists_workspace_bytes(nnz, m, S), dtype=torch.uint8, device=dev)
+            _lib.check(lib.tmf_wmrb_entry_lists(_lib.ptr(plan.user_of), _lib.ptr(plan.col_u), _lib.ptr(plan.val_u), nnz,
+                                                _lib.ptr(self.R), i32(m), i32(S), i32(n), i32(C), _lib.ptr(self.ent_row),
+                                                _lib.ptr(ent_id), _lib.ptr(ent_pos), _lib.ptr(rowptr), _lib.ptr(ws), ws.numel(),
+                                                _lib.stream_ptr()), lib)
+            del ws
         else:
-            ent_row, ent_w = e // S, nnz + e
-        self.S, self.R, self.user_chunks = S, R, C
-        self.ent_row = ent_row.to(torch.int32).contiguous()
-        self.ent_w = ent_w.to(torch.int64).contiguous()
+            upc = max(1, -(-m // C))
+            ku = plan.user_of.to(torch.int64)
+            kp = torch.where(plan.val_u > 0, (ku // upc) * n + plan.col_u.to(torch.int64), torch.full_like(ku, C * n))
+            ks = (torch.arange(m, dtype=torch.int64) // upc).repeat_interleave(S) * n + self.R.reshape(-1).to(torch.int64)
+            keys = torch.cat([kp, ks])
+            ent_id = torch.sort(keys, stable=True)[1]
+            rowptr = _excl_cumsum(torch.bincount(keys, minlength=C * n + 1))
+            owner = torch.cat([ku, torch.arange(m, dtype=torch.int64).repeat_interleave(S)])  # user of every entry id
+            self.ent_row = owner[ent_id].to(torch.int32)
+            ent_pos = torch.empty(E, dtype=torch.int32)
+            ent_pos[ent_id] = torch.arange(E, dtype=torch.int32)
+            ent_id = ent_id.to(torch.int32)
+        self.rowptr_e = rowptr[:C * n + 1].contiguous()  # the row behind them holds the stored values <= 0: never read
+        if self.sliced:
+            self.ent_pos = ent_pos
+            self.w_ent = torch.zeros(E, dtype=torch.float32, device=dev)
+        else:
+            self.ent_w = ent_id
         if C > 1:
             out_row = torch.arange(C * n, device=dev) % n
             self.seg_e = SegmentTable(self.rowptr_e, chunk, out_row=out_row, n_out=n)
         else:
             self.seg_e = SegmentTable(self.rowptr_e, chunk)
-        self.wbuf = torch.zeros(nnz + m * S, dtype=torch.float32, device=dev)
+        self.wbuf = torch.zeros(E, dtype=torch.float32, device=dev)
         self.delta = self.wbuf[:nnz]
         self.D = self.wbuf[nnz:].view(m, S)
+        self._lists = None
+
+    def lists(self, plan):
+        """tmf_slice_lists of the sliced pass (kept alive with the plan)."""
+        if self._lists is None:
+            m, S = self.R.shape
+            self._lists = _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(),
+                                          plan.col_u.data_ptr(), self.pos_off.data_ptr(), m, S, self.n_slices)
+        return ctypes.byref(self._lists)
 
     def D_in_model_order(self):
-        """D[u, s] indexed like the model's random_ind (the sliced pass keeps samples sorted by item)."""
-        if self.sample_perm is None:
+        """D[u, s] indexed like the model's random_ind (the sliced pass keeps every user's negatives sorted by item)."""
+        if not self.sliced:
             return self.D
+        perm = torch.sort(self.R_model.to(torch.int64), dim=1, stable=True)[1]
         out = torch.empty_like(self.D)
-        out.scatter_(1, self.sample_perm, self.D)
+        out.scatter_(1, perm, self.D)
         return out
 
 
@@ -292,18 +349,13 @@ class TrainState:
         self.slab = torch.empty(n_slab, self.ld, dtype=torch.float32, device=dev)
         n_part = max(plan.seg_u.nseg, plan.n_users, 1)
         self.loss_part = torch.zeros(n_part, dtype=torch.float32, device=dev)
-        self.user_ws = None
-        if wplan is not None:
-            ws = _lib.load_library().tmf_wmrb_user_workspace_bytes(plan.n_users, wplan.S, self.r)
-            if ws:
-                self.user_ws = torch.empty(ws // 4, dtype=torch.float32, device=dev)
-        if wplan is not None and wplan.n_slices > 1:
+        if wplan is not None and wplan.sliced:
             m, S = wplan.R.shape
-            self.sp = torch.empty(m, S, dtype=torch.float32, device=dev)
-            self.gpos = torch.empty(m, self.ld, dtype=torch.float32, device=dev)  # fp32 whatever the table dtype
+            self.sp = torch.empty(m, S, dtype=torch.float32, device=dev)      # sampled scores, R-sorted order
+            self.pk = torch.empty(max(plan.nnz, 1), dtype=torch.float32, device=dev)  # scores of the interactions, CSR order
             # gradU partials: one layer per slice, or (above PART_BUDGET bytes) a single layer summed by per-slice launches
             self.part_layers = wplan.n_slices if wplan.n_slices * m * self.ld * 4 <= PART_BUDGET else 1
-            self.part = torch.empty(self.part_layers * m, self.ld, dtype=torch.float32, device=dev)
+            self.part = torch.empty(self.part_layers * max(m, 1), self.ld, dtype=torch.float32, device=dev)
 
     def _pad(self, W, dev):
         W = torch.as_tensor(W).detach().to(device=dev, dtype=torch.float32)
@@ -370,23 +422,30 @@ def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=No
     _row_pass_finish(lib, p.seg_i, st.slab, st.V, V_out, r, item_epi, adam, s, st.sfx)
 
 
-def _wmrb_user_pass_sliced(lib, st, adam, c):
-    """Sliced user pass: scores -> hinge -> gradU -> finish (see csrc/tmf_wmrb.hip)."""
+def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None):
+    """Sliced user pass: scores -> hinge -> gradU (+ weights into entry order) -> finish (csrc/tmf_wmrb.hip, tmf_hinge.hip)."""
     p, w, r = st.plan, st.wplan, st.r
     i32 = ctypes.c_int32
     m, S, ns = p.n_users, w.S, w.n_slices
     s = _lib.stream_ptr()
-    _lib.check(getattr(lib, 'tmf_wmrb_scores2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S),
-                                                         _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp), r, s), lib)
-    _lib.check(getattr(lib, 'tmf_wmrb_hinge' + st.sfx)(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u),
-                                                       _lib.ptr(st.sp), i32(m), i32(S), c, _lib.ptr(st.U), _lib.ptr(st.V),
-                                                       _lib.ptr(st.gpos), _lib.ptr(w.delta), _lib.ptr(w.D),
-                                                       _lib.ptr(st.loss_part), r, s), lib)
-    _lib.check(getattr(lib, 'tmf_wmrb_gradu2' + st.sfx)(_lib.ptr(w.R), _lib.ptr(w.slice_off), i32(ns), i32(m), i32(S),
-                                                        _lib.ptr(w.D), _lib.ptr(st.V), _lib.ptr(st.part),
-                                                        int(st.part_layers == 1 and ns > 1), r, s), lib)
-    _lib.check(getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.gpos), _lib.ptr(st.part), i32(st.part_layers), i32(m),
-                                                        _lib.ptr(st.U), _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s), lib)
+    lists = w.lists(p)
+
+    def timed(name, rc_fn):
+        if prof:
+            prof.start(name)
+        _lib.check(rc_fn(), lib)
+        if prof:
+            prof.stop(name)
+    timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores3' + st.sfx)(lists, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp),
+                                                                            _lib.ptr(st.pk), r, s))
+    timed('wmrb_hinge', lambda: lib.tmf_wmrb_hinge2(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(st.pk), _lib.ptr(st.sp),
+                                                    i32(m), i32(S), c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), s))
+    nnz = p.nnz
+    timed('wmrb_gradu', lambda: getattr(lib, 'tmf_wmrb_gradu3' + st.sfx)(
+        lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(w.ent_pos[nnz:]), _lib.ptr(w.ent_pos[:nnz]), _lib.ptr(w.w_ent),
+        _lib.ptr(st.V), _lib.ptr(st.part), int(st.part_layers == 1 and ns > 1), r, s))
+    timed('wmrb_finish', lambda: getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.part), i32(st.part_layers), i32(m),
+                                                                          _lib.ptr(st.U), _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s))
 
 
 def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):
@@ -395,25 +454,30 @@ def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, pro
     s = _lib.stream_ptr()
     if prof:
         prof.start('wmrb_user_pass')
-    if w.n_slices > 1:
-        _wmrb_user_pass_sliced(lib, st, adam, c)
+    if w.sliced:
+        _wmrb_user_pass_sliced(lib, st, adam, c, prof)
     else:
         _lib.check(getattr(lib, 'tmf_wmrb_user_pass' + st.sfx)(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
                                               p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
                                               _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None,
-                                              _lib.ptr(st.user_ws), r, _lib.EPI_ADAM, adam, s), lib)
+                                              r, _lib.EPI_ADAM, adam, s), lib)
     if prof:
         prof.stop('wmrb_user_pass')
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)
     V_out = st.V_nxt if item_out is None else item_out
     if prof:
         prof.start('wmrb_item_pass')
-    _lib.check(getattr(lib, 'tmf_wsum_pass' + st.sfx)(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf),
+    weights, ent_w = (w.w_ent, None) if w.sliced else (w.wbuf, w.ent_w)   # entry order (streamed) or gathered through ent_w
+    _lib.check(getattr(lib, 'tmf_wsum_pass' + st.sfx)(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(ent_w), _lib.ptr(weights),
                                      _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(V_out), _lib.ptr(st.slab), r, item_epi,
                                      adam, s), lib)
     if prof:
         prof.stop('wmrb_item_pass')
+    if prof:
+        prof.start('wmrb_combine')
     _row_pass_finish(lib, w.seg_e, st.slab, st.V, V_out, r, item_epi, adam, s, st.sfx)
+    if prof:
+        prof.stop('wmrb_combine')
 
 
 def adam_constants(lr):

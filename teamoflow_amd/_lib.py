@@ -29,6 +29,12 @@ class Adam(ctypes.Structure):
                 ('eps', ctypes.c_float)]
 
 
+class SliceLists(ctypes.Structure):
+    _fields_ = [('R_sorted', ctypes.c_void_p), ('slice_off', ctypes.c_void_p), ('rowptr', ctypes.c_void_p),
+                ('col', ctypes.c_void_p), ('pos_off', ctypes.c_void_p), ('n_users', ctypes.c_int32),
+                ('n_samples', ctypes.c_int32), ('n_slices', ctypes.c_int32)]
+
+
 class Segments(ctypes.Structure):
     _fields_ = [('rowptr', ctypes.c_void_p), ('seg_row', ctypes.c_void_p), ('seg_chunk', ctypes.c_void_p),
                 ('seg_slab', ctypes.c_void_p), ('nseg', ctypes.c_int64), ('chunk', ctypes.c_int32),
@@ -37,6 +43,8 @@ class Segments(ctypes.Structure):
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _SEG = ctypes.POINTER(Segments)
+_SL = ctypes.POINTER(SliceLists)
+_I32, _SZ = ctypes.c_int32, ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/tmf.h declares (tests check this)
 SIGNATURES = {}
@@ -46,27 +54,30 @@ _BASE_SIGNATURES = {
     'tmf_padded_ld': (_I, [_I]),
     'tmf_padded_ld_bf16': (_I, [_I]),
     'tmf_adam_fresh': (Adam, [_F]),
-    'tmf_csr_build_workspace_bytes': (ctypes.c_size_t, [_L]),
-    'tmf_csr_build': (_I, [_P, _P, _L, ctypes.c_int32, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
-    'tmf_stable_order_workspace_bytes': (ctypes.c_size_t, [_L]),
-    'tmf_csc_perm': (_I, [_P, _L, ctypes.c_int32, _P, _P, _P, ctypes.c_size_t, _P]),
-    'tmf_stable_order_i32': (_I, [_P, _L, _L, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    'tmf_csr_build_workspace_bytes': (_SZ, [_L]),
+    'tmf_csr_build': (_I, [_P, _P, _L, _I32, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
+    'tmf_stable_order_workspace_bytes': (_SZ, [_L]),
+    'tmf_csc_perm': (_I, [_P, _L, _I32, _P, _P, _P, _SZ, _P]),
+    'tmf_stable_order_i32': (_I, [_P, _L, _L, _P, _P, _P, _P, _SZ, _P]),
+    'tmf_sort_samples_workspace_bytes': (_SZ, [_I32, _I32]),
+    'tmf_sort_samples': (_I, [_P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    'tmf_slice_offsets': (_I, [_P, _P, _L, _I32, _I32, _I32, _P, _P]),
+    'tmf_wmrb_entry_lists_workspace_bytes': (_SZ, [_L, _I32, _I32]),
+    'tmf_wmrb_entry_lists': (_I, [_P, _P, _P, _L, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
     'tmf_mse_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
-    'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _I, _I, Adam, _P]),
-    'tmf_wmrb_user_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, _I]),
-    'tmf_wmrb_hinge_f32': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
-    'tmf_wmrb_finish_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _I, _I, Adam, _P]),
-    'tmf_wmrb_scores2_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _P]),
-    'tmf_wmrb_gradu2_f32': (_I, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _I, _I, _P]),
+    'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_wmrb_user_pass_fits': (_I, [_I32, _I]),
+    'tmf_wmrb_scores3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _P]),
+    'tmf_wmrb_hinge2': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P]),
+    'tmf_wmrb_gradu3_f32': (_I, [_SL, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'tmf_wmrb_finish_f32': (_I, [_P, _I32, _I32, _P, _P, _I, _I, Adam, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
     'tmf_mse_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_bf16': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
-    'tmf_wmrb_user_pass_bf16': (_I, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _F, _P, _P, _P, _P, _P, _P, _P, _P,
-                                      _I, _I, Adam, _P]),
+    'tmf_wmrb_user_pass_bf16': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_adam_fresh_rows_bf16': (_I, [_P, _P, _L, _I, Adam, _P]),
     'tmf_sum_f32': (_I, [_P, _L, _P, _P]),
     'tmf_gather_rows_cols_f32': (_I, [_P, _P, _P, _L, _L, _L, _P]),
@@ -77,7 +88,7 @@ _BASE_SIGNATURES = {
 }
 
 SIGNATURES.update(_BASE_SIGNATURES)
-for _name in ('tmf_wmrb_scores2', 'tmf_wmrb_hinge', 'tmf_wmrb_gradu2', 'tmf_wmrb_finish'):
+for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_gradu3', 'tmf_wmrb_finish'):
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name + '_f32']
 
 _lib = None
@@ -106,7 +117,7 @@ def load_library():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.tmf_version() < 100:
+    if lib.tmf_version() < 200:
         raise EngineUnavailable('libtmf.so is older than this package')
     _lib = lib
     return lib

@@ -24,6 +24,26 @@ int check_launch(const char* what);
         }                                  \
     } while (0)
 
+// Kernels that ask for more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which applies to
+// the CURRENT device only: remember what was granted per device (one LdsGrant per kernel instance; a process may
+// drive several devices, and the call is cheap enough to repeat when two host threads race on a first use).
+struct LdsGrant {
+    size_t allowed[32];
+    LdsGrant() { for (size_t& a : allowed) a = 64 * 1024; }
+};
+inline int grant_dynamic_lds(const void* func, size_t lds, LdsGrant& g) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = -1;
+    if (dev >= 0 && lds <= g.allowed[dev]) return TMF_OK;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+        return TMF_E_LAUNCH;
+    }
+    if (dev >= 0) g.allowed[dev] = lds;
+    return TMF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row geometry.  A factor row of `ld` floats is read by a GROUP of G lanes, NV float4 per lane:
 // lane g of the group holds floats [4*(g + G*v), 4*(g + G*v) + 4) for v < NV, so every load
@@ -302,11 +322,6 @@ __device__ __forceinline__ void add(Frag<NV>& acc, const Frag<NV>& x) {
 
 template <int G>
 __device__ __forceinline__ float group_allsum(float v) {
-#ifdef TMF_SHUFFLE_ALLSUM
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-#endif
     if (G >= 2) v = TMF_DPP_ADD(v, 0xB1);   // quad_perm [1,0,3,2]
     if (G >= 4) v = TMF_DPP_ADD(v, 0x4E);   // quad_perm [2,3,0,1]
     if (G >= 8) v = TMF_DPP_ADD(v, 0x141);  // row_half_mirror

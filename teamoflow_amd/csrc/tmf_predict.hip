@@ -256,16 +256,8 @@ extern "C" int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, i
         set_error("topk: full ranking of %lld columns needs %zu bytes of LDS (max 163840); use k <= 64", (long long)cols, lds);
         return TMF_E_UNSUPPORTED;
     }
-    static size_t allowed = 64 * 1024;
-    if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-            return TMF_E_LAUNCH;
-        }
-        allowed = lds;
-    }
+    static LdsGrant grant;
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_sort_rows), lds, grant)) return rc;
     const int threads = npow2 / 2 < 1024 ? (npow2 / 2 < 64 ? 64 : npow2 / 2) : 1024;
     hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)rows), dim3(threads), lds, (hipStream_t)stream, X, cols, ldx, k,
                        clamp_negatives, npow2, out_idx, out_val);
@@ -575,13 +567,8 @@ static int launch_predict_topk_impl(const float* A, const float* B, int64_t m, i
                                int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
     const size_t lds = sizeof(float) * (3 * FBK * FLD + FBM) + sizeof(int) * (FBM + 4) + 8 * (size_t)FCAP * FBM +
                        8 * (size_t)k * FBM;
-    static size_t allowed = 64 * 1024;
-    if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk<NCH, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return TMF_E_LAUNCH; }
-        allowed = lds;
-    }
+    static LdsGrant grant;  // per template instance
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk<NCH, MODE>), lds, grant)) return rc;
     const int64_t blocks = (m + FBM - 1) / FBM;
     hipLaunchKernelGGL((k_predict_topk<NCH, MODE>), dim3((unsigned)blocks), dim3(256), lds, stream, A, B, m, n, K, lda, ldb, k,
                        clamp, out_idx, out_val);
@@ -861,13 +848,8 @@ static int launch_predict_topk_bf16_impl(const void* A, const void* B, int64_t m
                                     int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
     const size_t lds = (size_t)3 * HBN * HROW + sizeof(float) * HBM_ + sizeof(int) * HBM_ + 8 * (size_t)HCAP * HBM_ +
                        8 * (size_t)k * HBM_;
-    static size_t allowed = 64 * 1024;
-    if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_predict_topk_bf16<NCH, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return TMF_E_LAUNCH; }
-        allowed = lds;
-    }
+    static LdsGrant grant;  // per template instance
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_bf16<NCH, MODE>), lds, grant)) return rc;
     const int64_t blocks = (m + HBM_ - 1) / HBM_;
     hipLaunchKernelGGL((k_predict_topk_bf16<NCH, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, (const __bf16*)A,
                        (const __bf16*)B, m, n, K, lda, ldb, k, clamp, out_idx, out_val);

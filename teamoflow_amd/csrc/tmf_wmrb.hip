@@ -64,16 +64,13 @@ __device__ __forceinline__ float4 select_ge_x4(float sps, const float4 c, const 
     return r;
 }
 
-// SLICED = true is the middle kernel of the sliced user pass (see k_wmrb_slice below): sp[u, :] comes from
-// global memory (sp_in) instead of phase 1, phase 3 is skipped, and the caller asks for the gradient
-// epilogue so that U_out receives only the positives' part  sum_k delta_k V[j_k].
-// BIG = true: n_samples too large for LDS - sp[u, :] and D[u, :] live in global memory (sp_ws row of
-// round4(S) floats per user, D's own row); same arithmetic, only the storage changes.
-template <int G, int NV, typename T, bool SLICED, bool BIG>
+// (Catalogs whose V table is larger than the L2s, or sample counts whose scores do not fit LDS, go through the sliced
+// pass below instead, whose hinge step is O((S + P) log P) per user - csrc/tmf_hinge.hip.)
+template <int G, int NV, typename T>
 __device__ __forceinline__ void wmrb_user_body(
     const int64_t u, char* smem_raw,
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int32_t* __restrict__ R, const float* __restrict__ sp_in, float* __restrict__ sp_ws, int S, float c,
+    const int32_t* __restrict__ R, int S, float c,
     const T* __restrict__ U_old,
     const T* __restrict__ V_old, void* __restrict__ U_out, float* __restrict__ delta,
     float* __restrict__ Dg, float* __restrict__ loss_part, float* __restrict__ pos_part, int epi,
@@ -82,15 +79,15 @@ __device__ __forceinline__ void wmrb_user_body(
     constexpr int NGB = NG * kWaves;    // groups per block
     constexpr int LD = 4 * G * NV;
     const int S4 = round4(S), SP = sp_padded(S);
-    float* sp = BIG ? sp_ws + u * (int64_t)SP : reinterpret_cast<float*>(smem_raw);   // [SP] scores, tail -inf
-    float* Dl = BIG ? Dg + u * (int64_t)S : sp + SP;                                   // [S]  D[u, :]
-    float* c1 = BIG ? reinterpret_cast<float*>(smem_raw) : Dl + S4;  // [kPosChunk] 1 - p_k, -inf for non-positives
+    float* sp = reinterpret_cast<float*>(smem_raw);   // [SP] scores, tail -inf
+    float* Dl = sp + SP;                              // [S]  D[u, :]
+    float* c1 = Dl + S4;                              // [kPosChunk] 1 - p_k, -inf for non-positives
     float* wl = c1 + kPosChunk;                       // [kPosChunk] w_k
     float* dl = wl + kPosChunk;                       // [kPosChunk] delta_k
     int* ci = reinterpret_cast<int*>(dl + kPosChunk); // [kPosChunk] item of a positive entry, -1 otherwise
-    int* Rl = ci + kPosChunk;                         // [S4] the user's negatives (fused pass only): the row gathers
-                                                      //      then depend on an LDS read, not on a second global load
-    float* pm = reinterpret_cast<float*>(Rl + ((SLICED || BIG) ? 0 : S4));  // [2 kWaves][32] partials of M_k
+    int* Rl = ci + kPosChunk;                         // [S4] the user's negatives: the row gathers then depend on an
+                                                      //      LDS read, not on a second global load
+    float* pm = reinterpret_cast<float*>(Rl + S4);    // [2 kWaves][32] partials of M_k
     int* pc = reinterpret_cast<int*>(pm + kWaves * 64);                     // [2 kWaves][32] partials of cnt_k
     float* red = reinterpret_cast<float*>(pc + kWaves * 64);                // [kWaves][LD] + 2*kWaves
 
@@ -115,14 +112,9 @@ __device__ __forceinline__ void wmrb_user_body(
         Frag<NV> x;
         load_row<G, NV>(x, U_old, u, g);
         // ---- phase 1 ----
-        if (SLICED) {
-            for (int s = tid; s < S; s += kThreads) sp[s] = sp_in[u * (int64_t)S + s];
-        } else if (!BIG) {
-            for (int s = tid; s < S; s += kThreads) Rl[s] = Ru[s];
-            __syncthreads();
-        }
-        const int32_t* Ri = BIG ? Ru : Rl;
-        if (!SLICED)
+        for (int s = tid; s < S; s += kThreads) Rl[s] = Ru[s];
+        __syncthreads();
+        const int32_t* Ri = Rl;
         for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
             Raw<NV, T> raw[kUnrollW];
 #pragma unroll
@@ -269,7 +261,6 @@ __device__ __forceinline__ void wmrb_user_body(
             __syncthreads();
         }
         // ---- phase 3 ----
-        if (!SLICED)
         for (int s0 = gid; s0 < S; s0 += NGB * kUnrollW) {
             Raw<NV, T> raw[kUnrollW];
             float d[kUnrollW];
@@ -286,8 +277,7 @@ __device__ __forceinline__ void wmrb_user_body(
                 axpy<NV>(acc, d[t], y);
             }
         }
-        if (!BIG)
-            for (int s = tid; s < S; s += kThreads) __builtin_nontemporal_store(Dl[s], Dg + u * (int64_t)S + s);
+        for (int s = tid; s < S; s += kThreads) __builtin_nontemporal_store(Dl[s], Dg + u * (int64_t)S + s);
     }
 
     // ---- block reduction of gU (groups of a wave, then the four waves in order) and of the loss ----
@@ -326,75 +316,61 @@ __device__ __forceinline__ void wmrb_user_body(
     }
 }
 
-template <int G, int NV, typename T, bool SLICED, bool BIG>
+template <int G, int NV, typename T>
 __global__ __launch_bounds__(kThreads) void k_wmrb_user(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int32_t* __restrict__ R, const float* __restrict__ sp_in, float* __restrict__ sp_ws, int S, float c,
+    const int32_t* __restrict__ R, int S, float c,
     const T* __restrict__ U_old, const T* __restrict__ V_old, void* __restrict__ U_out, float* __restrict__ delta,
     float* __restrict__ Dg, float* __restrict__ loss_part, float* __restrict__ pos_part, int epi, tmf_adam adam) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    wmrb_user_body<G, NV, T, SLICED, BIG>(blockIdx.x, smem_raw, rowptr, col, val, R, sp_in, sp_ws, S, c, U_old, V_old, U_out,
-                                          delta, Dg, loss_part, pos_part, epi, adam);
+    wmrb_user_body<G, NV, T>(blockIdx.x, smem_raw, rowptr, col, val, R, S, c, U_old, V_old, U_out, delta, Dg, loss_part,
+                             pos_part, epi, adam);
 }
 
-static size_t wmrb_user_lds(int S, int ld, bool big, bool sliced = false) {
-    // sp + D (unless in global memory), c1 / w / delta / item per chunk entry, the user's negatives, the reduction
-    return sizeof(float) * ((big ? 0 : (size_t)sp_padded(S) + round4(S)) + 4 * kPosChunk +
-                            ((sliced || big) ? 0 : (size_t)round4(S)) + 2 * kWaves * 64 + (size_t)kWaves * ld + 2 * kWaves);
+static size_t wmrb_user_lds(int S, int ld) {
+    // sp + D, c1 / w / delta / item per chunk entry, the user's negatives, the reduction
+    return sizeof(float) * ((size_t)sp_padded(S) + round4(S) + 4 * kPosChunk + (size_t)round4(S) + 2 * kWaves * 64 +
+                            (size_t)kWaves * ld + 2 * kWaves);
 }
 
-template <int G, int NV, typename T, bool SLICED>
+template <int G, int NV, typename T>
 static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
-                            const float* sp_in, float* sp_ws, int32_t n_users, int32_t S, float c, const T* U_old, const T* V_old,
+                            int32_t n_users, int32_t S, float c, const T* U_old, const T* V_old,
                             void* U_out, float* delta, float* D, float* loss_part, float* pos_part, int epi,
                             tmf_adam adam, hipStream_t stream) {
-    const bool big = wmrb_user_lds(S, 4 * G * NV, false) > 160 * 1024;
-    const size_t lds = wmrb_user_lds(S, 4 * G * NV, big, SLICED);
-    if (big) {
-        if (SLICED || sp_ws == nullptr) {
-            set_error("wmrb_user_pass: n_samples=%d does not fit LDS; pass the workspace of tmf_wmrb_user_workspace_bytes()", S);
-            return TMF_E_INVALID;
-        }
-        hipLaunchKernelGGL((k_wmrb_user<G, NV, T, false, true>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr,
-                           col, val, R, sp_in, sp_ws, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
-        return check_launch("tmf_wmrb_user_pass_f32");
+    const size_t lds = wmrb_user_lds(S, 4 * G * NV);
+    if (lds > 160 * 1024) {
+        set_error("wmrb_user_pass: n_samples=%d does not fit LDS (%zu bytes); use the sliced pass (tmf_wmrb_scores3 ...)", S, lds);
+        return TMF_E_UNSUPPORTED;
     }
-    static size_t allowed = 64 * 1024;  // per template instance
-    if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, T, SLICED, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-            return TMF_E_LAUNCH;
-        }
-        allowed = lds;
-    }
-    hipLaunchKernelGGL((k_wmrb_user<G, NV, T, SLICED, false>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
-                       val, R, sp_in, sp_ws, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
-    return check_launch(SLICED ? "tmf_wmrb_hinge_f32" : "tmf_wmrb_user_pass_f32");
+    static LdsGrant grant;  // per template instance
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, T>), lds, grant)) return rc;
+    hipLaunchKernelGGL((k_wmrb_user<G, NV, T>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
+                       val, R, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
+    return check_launch("tmf_wmrb_user_pass");
 }
 
 // ---------------------------------------------------------------------------------------------
 // Sliced user pass.  The fused kernel above gathers V rows over the whole item table (51 MB at
 // 100K x 128: served by the Infinity Cache at ~8 TB/s).  Here the S negatives of every user are kept
-// sorted by item id and the catalog is cut into slices of ~2-4 MB of V rows; blocks are numbered
-// slice-major, so the workgroups resident at any moment gather from ONE slice, which the XCD L2s hold
-// (13-14 TB/s measured for the same gather, profiles/r01_user_chunk_sweep.txt).  Three kernels:
-//   k_wmrb_scores2        sp[u, s]  = <U[u], V[R[u, s]]>            for s in the slice      -> global
-//   k_wmrb_user<SLICED>   hinge math on sp (+ positives): delta, D, loss, gpos[u] = sum_k delta_k V[j_k]
-//   k_wmrb_gradu2         part[slice][u] = sum_{s in slice} D[u, s] V[R[u, s]]              -> global
-//   k_wmrb_finish         gU[u] = gpos[u] + sum_slice part[slice][u] (fixed order) -> epilogue
+// sorted by item id (the interactions of a user are sorted by item anyway) and the catalog is cut into
+// slices of ~4 MB of V rows; blocks are numbered slice-major, so the workgroups resident at any moment
+// gather from ONE slice, which the XCD L2s hold (20 TB/s measured for these gathers).  Kernels:
+//   k_wmrb_scores3   sp[u, s] = <U[u], V[R[u, s]]> for the negatives in the slice, p[k] = <U[u], V[j_k]> for the
+//                    user's interactions in the slice                                             -> global
+//   k_wmrb_hinge2    (tmf_hinge.hip) sp, p -> delta, D, loss; touches no table
+//   k_wmrb_gradu3    part[slice][u] = sum_{s in slice} D[u, s] V[R[u, s]] + sum_{k in slice} delta_k V[j_k]; on the
+//                    way every weight is also stored at its position in the item-side entry lists (w_ent), so the
+//                    item pass streams its weights instead of gathering them 4 bytes at a time
+//   k_wmrb_finish    gU[u] = sum_slice part[slice][u] (fixed order) -> epilogue
 // Block placement is used for speed only; any dispatch order gives the same bits.
-// ---------------------------------------------------------------------------------------------
-constexpr int kSliceUsers = 128;  // users per workgroup of k_wmrb_slice
-
-// ---------------------------------------------------------------------------------------------
-// (An in-launch variant - scores + hinge in one launch, the workgroup publishing a 128-user group's last slice
-// running the hinge step behind an agent-scope release/acquire ticket - was measured slower, 93 ms against
-// 46 + 40 ms for the pair, and removed; see profiles/r01_sliced_user_pass.txt.)
-// Both slice roles stage the (user, slice) range's item ids (and D) through LDS so that a row gather
+// Both slice roles stage the ids (and weights) of a (user, slice) range through LDS so that a row gather
 // depends on an LDS read only.
+// (An in-launch variant - scores + hinge in one launch behind an agent-scope ticket - was measured slower and
+// removed; see profiles/r01_sliced_user_pass.txt.)
 // ---------------------------------------------------------------------------------------------
+constexpr int kSliceUsers = 128;  // users per workgroup
+
 template <int G>
 struct Stage {
     static constexpr int tile = 8 * G;  // entries staged per lane group and step: 16 KB of LDS per workgroup for every G
@@ -402,122 +378,159 @@ struct Stage {
 
 template <int G>
 __device__ __forceinline__ int* slice_stage(char* smem_raw, int gid) {
-    return reinterpret_cast<int*>(smem_raw) + gid * 2 * Stage<G>::tile;  // [ids | D] per lane group
+    return reinterpret_cast<int*>(smem_raw) + gid * 2 * Stage<G>::tile;  // [ids | weights] per lane group
 }
 
+// One list (the negatives or the interactions of a user that fall into the slice): entries [beg, end) of `list`.
+//   GRADU = false: out[t] = <x, V[list[t]]>
+//   GRADU = true : acc += wts[t] V[list[t]] (rows with weight 0 are not loaded); w_ent[entpos[t]] = wts[t] when
+//                  entpos is given and entpos[t] >= 0
 template <int G, int NV, typename T, bool GRADU>
-__device__ __forceinline__ void wmrb_slice_body(
-    char* smem_raw, const int64_t sl, const int64_t ubeg, const int64_t uend, const int32_t* __restrict__ R,
-    const int32_t* __restrict__ off, int n_slices, int64_t part_users, int64_t part_u0, int S,
-    const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp, const float* __restrict__ D,
-    float* __restrict__ part, int accumulate = 0) {
-    constexpr int NG = 64 / G, NGB = NG * kWaves, kStageTile = Stage<G>::tile;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane & (G - 1), gid = wave * NG + lane / G;
-    int* ids = slice_stage<G>(smem_raw, gid);
-    float* dst = reinterpret_cast<float*>(ids + kStageTile);
-    for (int64_t u = ubeg + gid; u < uend; u += NGB) {
-        const int beg = off[u * (n_slices + 1) + sl], end = off[u * (n_slices + 1) + sl + 1];
-        const int32_t* Ru = R + u * (int64_t)S;
-        Frag<NV> x, acc;
-        if (GRADU) zero<NV>(acc);
-        else load_row<G, NV>(x, U, u, g);
-        for (int t0 = beg; t0 < end; t0 += kStageTile) {
-            const int cnt = (end - t0 < kStageTile) ? end - t0 : kStageTile;
-            for (int e = g; e < cnt; e += G) {
-                ids[e] = Ru[t0 + e];
-                if (GRADU) dst[e] = D[u * (int64_t)S + t0 + e];
-            }
-            float keep = 0.f;  // scores: lane g keeps the score of entry (e & (G-1)) == g until G of them are complete
-            for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
-                Raw<NV, T> raw[kUnrollW];
-                float d[kUnrollW];
-                // the four ids (and weights) of this step in ONE LDS read each (e0 % 4 == 0, 16-byte aligned tile buffers;
-                // slots past cnt hold stale values and are never used): one LDS round trip before the four row loads
-                // instead of four dependent ones
-                static_assert(kUnrollW == 4, "vector LDS reads assume four entries per step");
-                const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);
-                const float4 w4 = GRADU ? *reinterpret_cast<const float4*>(dst + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const int idv[4] = {id4.x, id4.y, id4.z, id4.w};
-                const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                for (int t = 0; t < kUnrollW; ++t) {
-                    const int e = e0 + t;
-                    bool want = e < cnt;
-                    d[t] = 0.f;
-                    if (GRADU && want) { d[t] = wv[t]; want = d[t] != 0.f; }
-                    load_raw<G, NV>(raw[t], V, want ? idv[t] : 0, g);
-                }
-#pragma unroll
-                for (int t = 0; t < kUnrollW; ++t) {
-                    Frag<NV> y;
-                    to_frag<NV>(y, raw[t]);
-                    if (GRADU) {
-                        axpy<NV>(acc, d[t], y);
-                    } else {
-                        const int e = e0 + t;
-                        const float p = group_allsum<G>(dot_partial<NV>(x, y));
-                        if (g == (e & (G - 1))) keep = p;
-                        // a full run of G scores (or the tail of the tile): one contiguous 4*G-byte store per group
-                        if (e < cnt && ((e & (G - 1)) == G - 1 || e == cnt - 1)) {
-                            if (g <= (e & (G - 1))) __builtin_nontemporal_store(keep, sp + u * (int64_t)S + t0 + (e & ~(G - 1)) + g);
-                        }
-                    }
+__device__ __forceinline__ void slice_list(int* ids, float* dst, const int32_t* __restrict__ list, int beg, int end,
+                                           const T* __restrict__ V, const Frag<NV>& x, Frag<NV>& acc,
+                                           float* __restrict__ out, const float* __restrict__ wts,
+                                           const int32_t* __restrict__ entpos, float* __restrict__ w_ent, int g) {
+    constexpr int kStageTile = Stage<G>::tile;
+    for (int t0 = beg; t0 < end; t0 += kStageTile) {
+        const int cnt = (end - t0 < kStageTile) ? end - t0 : kStageTile;
+        for (int e = g; e < cnt; e += G) {
+            ids[e] = list[t0 + e];
+            if (GRADU) {
+                const float w = wts[t0 + e];
+                dst[e] = w;
+                if (entpos != nullptr) {
+                    const int ep = entpos[t0 + e];
+                    if (ep >= 0) w_ent[ep] = w;
                 }
             }
         }
-        if (GRADU) {
-            if (accumulate == 0) {
-                store_row_f32<G, NV, T>(acc, part, sl * part_users + (u - part_u0), g);
-            } else {  // one launch per slice: part is a single [users, ld] layer summed in slice order
-                if (accumulate == 2) {
-                    Frag<NV> prev;
-                    load_row_f32<G, NV, T>(prev, part, u - part_u0, g);
-                    add<NV>(prev, acc);
-                    acc = prev;
+        float keep = 0.f;  // scores: lane g keeps the score of entry (e & (G-1)) == g until G of them are complete
+        for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
+            Raw<NV, T> raw[kUnrollW];
+            float d[kUnrollW];
+            // the four ids (and weights) of this step in ONE LDS read each (e0 % 4 == 0, 16-byte aligned tile buffers;
+            // slots past cnt hold stale values and are never used): one LDS round trip before the four row loads
+            static_assert(kUnrollW == 4, "vector LDS reads assume four entries per step");
+            const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);
+            const float4 w4 = GRADU ? *reinterpret_cast<const float4*>(dst + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int idv[4] = {id4.x, id4.y, id4.z, id4.w};
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) {
+                const int e = e0 + t;
+                bool want = e < cnt;
+                d[t] = 0.f;
+                if (GRADU && want) { d[t] = wv[t]; want = d[t] != 0.f; }
+                load_raw<G, NV>(raw[t], V, want ? idv[t] : 0, g);
+            }
+#pragma unroll
+            for (int t = 0; t < kUnrollW; ++t) {
+                Frag<NV> y;
+                to_frag<NV>(y, raw[t]);
+                if (GRADU) {
+                    axpy<NV>(acc, d[t], y);
+                } else {
+                    const int e = e0 + t;
+                    const float pr = group_allsum<G>(dot_partial<NV>(x, y));
+                    if (g == (e & (G - 1))) keep = pr;
+                    // a full run of G scores (or the tail of the tile): one contiguous 4*G-byte store per group
+                    if (e < cnt && ((e & (G - 1)) == G - 1 || e == cnt - 1)) {
+                        if (g <= (e & (G - 1))) __builtin_nontemporal_store(keep, out + t0 + (e & ~(G - 1)) + g);
+                    }
                 }
-                store_row_f32<G, NV, T>(acc, part, u - part_u0, g);
             }
         }
     }
 }
 
+// Arguments shared by the two slice kernels: the per-user sorted negatives with their slice offsets, and the CSR of the
+// interactions (sorted by item inside a user) with theirs.
+struct SliceLists {
+    const int32_t* R;        // [n_users, S] negatives, ascending item id per user
+    const int32_t* off;      // [n_users, n_slices + 1] first negative of every slice
+    const int64_t* rowptr;   // [n_users + 1]
+    const int32_t* col;      // [nnz]
+    const int32_t* poff;     // [n_users, n_slices + 1] first interaction of every slice, relative to rowptr[u]
+    int n_slices, S;
+    int64_t n_users, n_groups;
+};
+
 template <int G, int NV, typename T>
-__global__ __launch_bounds__(kThreads) void k_wmrb_scores2(
-    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
-    int64_t n_groups, const T* __restrict__ U, const T* __restrict__ V, float* __restrict__ sp) {
+__global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T* __restrict__ U, const T* __restrict__ V,
+                                                           float* __restrict__ sp, float* __restrict__ p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int64_t sl = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    constexpr int NG = 64 / G, NGB = NG * kWaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane & (G - 1), gid = wave * NG + lane / G;
+    int* ids = slice_stage<G>(smem_raw, gid);
+    float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
+    const int64_t sl = blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
     const int64_t ubeg = grp * kSliceUsers;
-    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
-    wmrb_slice_body<G, NV, T, false>(smem_raw, sl, ubeg, uend, R, off, n_slices, 0, 0, S, U, V, sp, nullptr, nullptr);
+    const int64_t uend = (ubeg + kSliceUsers < a.n_users) ? ubeg + kSliceUsers : a.n_users;
+    for (int64_t u = ubeg + gid; u < uend; u += NGB) {
+        const int64_t o = u * (a.n_slices + 1) + sl;
+        const int nb = a.off[o], ne = a.off[o + 1], pb = a.poff[o], pe = a.poff[o + 1];
+        if (nb == ne && pb == pe) continue;
+        Frag<NV> x, none;
+        load_row<G, NV>(x, U, u, g);
+        slice_list<G, NV, T, false>(ids, dst, a.R + u * (int64_t)a.S, nb, ne, V, x, none, sp + u * (int64_t)a.S, nullptr,
+                                    nullptr, nullptr, g);
+        const int64_t rb = a.rowptr[u];
+        slice_list<G, NV, T, false>(ids, dst, a.col + rb, pb, pe, V, x, none, p + rb, nullptr, nullptr, nullptr, g);
+    }
 }
 
 // slice_first >= 0: this launch covers ONE slice (slice_first) and adds into the single-layer `part`
 // (plain read-modify-write; launches of consecutive slices are ordered by the stream).
 template <int G, int NV, typename T>
-__global__ __launch_bounds__(kThreads) void k_wmrb_gradu2(
-    const int32_t* __restrict__ R, const int32_t* __restrict__ off, int n_slices, int64_t n_users, int S,
-    int64_t n_groups, const T* __restrict__ V, const float* __restrict__ D, float* __restrict__ part, int slice_first) {
+__global__ __launch_bounds__(kThreads) void k_wmrb_gradu3(SliceLists a, const T* __restrict__ V, const float* __restrict__ D,
+                                                          const float* __restrict__ delta, const int32_t* __restrict__ eps,
+                                                          const int32_t* __restrict__ epp, float* __restrict__ w_ent,
+                                                          float* __restrict__ part, int slice_first) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int64_t sl = (slice_first >= 0) ? slice_first : blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    constexpr int NG = 64 / G, NGB = NG * kWaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane & (G - 1), gid = wave * NG + lane / G;
+    int* ids = slice_stage<G>(smem_raw, gid);
+    float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
+    const int64_t sl = (slice_first >= 0) ? slice_first : blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
+    const int accumulate = slice_first < 0 ? 0 : (slice_first == 0 ? 1 : 2);
     const int64_t ubeg = grp * kSliceUsers;
-    const int64_t uend = (ubeg + kSliceUsers < n_users) ? ubeg + kSliceUsers : n_users;
-    wmrb_slice_body<G, NV, T, true>(smem_raw, sl, ubeg, uend, R, off, n_slices, n_users, 0, S, nullptr, V, nullptr, D, part,
-                                    slice_first < 0 ? 0 : (slice_first == 0 ? 1 : 2));
+    const int64_t uend = (ubeg + kSliceUsers < a.n_users) ? ubeg + kSliceUsers : a.n_users;
+    for (int64_t u = ubeg + gid; u < uend; u += NGB) {
+        const int64_t o = u * (a.n_slices + 1) + sl;
+        const int nb = a.off[o], ne = a.off[o + 1], pb = a.poff[o], pe = a.poff[o + 1];
+        Frag<NV> acc, none;
+        zero<NV>(acc);
+        const int64_t us = u * (int64_t)a.S, rb = a.rowptr[u];
+        slice_list<G, NV, T, true>(ids, dst, a.R + us, nb, ne, V, none, acc, nullptr, D + us, eps ? eps + us : nullptr, w_ent, g);
+        slice_list<G, NV, T, true>(ids, dst, a.col + rb, pb, pe, V, none, acc, nullptr, delta + rb, epp ? epp + rb : nullptr,
+                                   w_ent, g);
+        if (accumulate == 0) {
+            store_row_f32<G, NV, T>(acc, part, sl * a.n_users + u, g);
+        } else {  // one launch per slice: part is a single [users, ld] layer summed in slice order
+            if (accumulate == 2) {
+                Frag<NV> prev;
+                load_row_f32<G, NV, T>(prev, part, u, g);
+                add<NV>(prev, acc);
+                acc = prev;
+            }
+            store_row_f32<G, NV, T>(acc, part, u, g);
+        }
+    }
 }
 
 template <int G, int NV, typename T>
-__global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* __restrict__ gpos, const float* __restrict__ part,
-                                                          int n_slices, int64_t n_users, const T* __restrict__ U_old,
-                                                          void* __restrict__ U_out, int epi, tmf_adam adam) {
+__global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* __restrict__ part, int n_slices, int64_t n_users,
+                                                          const T* __restrict__ U_old, void* __restrict__ U_out, int epi,
+                                                          tmf_adam adam) {
     constexpr int NG = 64 / G, NGB = NG * kWaves;
     const int lane = threadIdx.x & 63, g = lane & (G - 1);
     const int64_t u = (int64_t)blockIdx.x * NGB + (threadIdx.x >> 6) * NG + lane / G;
     if (u >= n_users) return;
     Frag<NV> acc;
-    load_row_f32<G, NV, T>(acc, gpos, u, g);
-    for (int sl = 0; sl < n_slices; ++sl) {
+    load_row_f32<G, NV, T>(acc, part, u, g);
+    for (int sl = 1; sl < n_slices; ++sl) {
         Frag<NV> y;
         load_row_f32<G, NV, T>(y, part, sl * n_users + u, g);
         add<NV>(acc, y);
@@ -529,133 +542,120 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* __restric
 
 using namespace tmf;
 
-extern "C" size_t tmf_wmrb_user_workspace_bytes(int32_t n_users, int32_t S, int n_components) {
-    const RowGeom geom = row_geom(n_components);
-    if (geom.ld == 0 || S <= 0 || n_users <= 0) return 0;
-    if (wmrb_user_lds(S, geom.ld, false) <= 160 * 1024) return 0;
-    return (size_t)n_users * sp_padded(S) * sizeof(float);
-}
-
 template <typename T>
 static int wmrb_user_pass_impl(const int64_t* rowptr, const int32_t* col, const float* val, const int32_t* R,
                                int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old, void* U_out,
-                               float* delta, float* D, float* loss_part, float* pos_part, float* workspace,
-                               int n_components, int epi, tmf_adam adam, void* stream) {
+                               float* delta, float* D, float* loss_part, float* pos_part, int n_components, int epi,
+                               tmf_adam adam, void* stream) {
     if (n_users == 0) return TMF_OK;
     TMF_REQUIRE(n_users > 0 && S > 0, "wmrb_user_pass: n_users=%d S=%d", n_users, S);
     TMF_REQUIRE(rowptr && R && U_old && V_old && U_out && D, "wmrb_user_pass: null pointer");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_user_pass: bad epilogue %d", epi);
     const RowGeom geom = row_geom_of<T>(n_components);
-#define CALL(G_, NV_)                                                                                                 \
-    return launch_wmrb_user<G_, NV_, T, false>(rowptr, col, val, R, nullptr, workspace, n_users, S, c, (const T*)U_old, \
-                                               (const T*)V_old, U_out, delta, D, loss_part, pos_part, epi, adam,       \
-                                               (hipStream_t)stream)
+#define CALL(G_, NV_)                                                                                                  \
+    return launch_wmrb_user<G_, NV_, T>(rowptr, col, val, R, n_users, S, c, (const T*)U_old, (const T*)V_old, U_out, \
+                                        delta, D, loss_part, pos_part, epi, adam, (hipStream_t)stream)
     TMF_DISPATCH(T, geom, CALL);
 #undef CALL
     return TMF_OK;
+}
+
+extern "C" int tmf_wmrb_user_pass_fits(int32_t S, int n_components) {
+    const RowGeom geom = row_geom(n_components);
+    return geom.ld != 0 && S > 0 && wmrb_user_lds(S, geom.ld) <= 160 * 1024;
 }
 
 extern "C" int tmf_wmrb_user_pass_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                       const int32_t* R, int32_t n_users, int32_t S, float c,
                                       const float* U_old, const float* V_old, float* U_out, float* delta,
-                                      float* D, float* loss_part, float* pos_part, float* workspace,
+                                      float* D, float* loss_part, float* pos_part,
                                       int n_components, int epi, tmf_adam adam, void* stream) {
     return wmrb_user_pass_impl<float>(rowptr, col, val, R, n_users, S, c, U_old, V_old, U_out, delta, D, loss_part,
-                                      pos_part, workspace, n_components, epi, adam, stream);
+                                      pos_part, n_components, epi, adam, stream);
 }
 extern "C" int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col, const float* val,
                                        const int32_t* R, int32_t n_users, int32_t S, float c,
                                        const void* U_old, const void* V_old, void* U_out, float* delta,
-                                       float* D, float* loss_part, float* pos_part, float* workspace,
+                                       float* D, float* loss_part, float* pos_part,
                                        int n_components, int epi, tmf_adam adam, void* stream) {
     return wmrb_user_pass_impl<__bf16>(rowptr, col, val, R, n_users, S, c, U_old, V_old, U_out, delta, D, loss_part,
-                                       pos_part, workspace, n_components, epi, adam, stream);
+                                       pos_part, n_components, epi, adam, stream);
 }
 
-
-
-
-
-
-
-
-// ---- staged sliced pass: storage-type generic implementations + the _f32 / _bf16 entry points ----
-template <typename T>
-static int wmrb_scores2_impl(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices, int32_t n_users,
-                             int32_t S, const void* U, const void* V, float* sp, int n_components, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(R_sorted && slice_off && U && V && sp && n_slices > 0 && S > 0, "wmrb_scores2: bad arguments");
-    const RowGeom geom = row_geom_of<T>(n_components);
-    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
-    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_scores2: grid too large");
-    const size_t lds = (size_t)(64 / (geom.G ? geom.G : 1)) * kWaves * 2 * 8 * geom.G * sizeof(int);
-#define CALL(G_, NV_)                                                                                            \
-    hipLaunchKernelGGL((k_wmrb_scores2<G_, NV_, T>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,   \
-                       (const T*)U, (const T*)V, sp)
-    TMF_DISPATCH(T, geom, CALL);
-#undef CALL
-    return check_launch("tmf_wmrb_scores2");
-}
-
-template <typename T>
-static int wmrb_hinge_impl(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp, int32_t n_users,
-                           int32_t S, float c, const void* U_old, const void* V_old, float* gpos, float* delta, float* D,
-                           float* loss_part, int n_components, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(rowptr && sp && U_old && V_old && gpos && D && n_users > 0 && S > 0, "wmrb_hinge: bad arguments");
-    const RowGeom geom = row_geom_of<T>(n_components);
-    tmf_adam none = {0.f, 0.f, 0.f, 0.f};
-#define CALL(G_, NV_)                                                                                                     \
-    return launch_wmrb_user<G_, NV_, T, true>(rowptr, col, val, nullptr, sp, nullptr, n_users, S, c, (const T*)U_old,       \
-                                              (const T*)V_old, gpos, delta, D, loss_part, nullptr, TMF_EPI_GRAD, none,     \
-                                              (hipStream_t)stream)
-    TMF_DISPATCH(T, geom, CALL);
-#undef CALL
+// ---- sliced pass: storage-type generic implementations + the _f32 / _bf16 entry points ----
+static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what) {
+    TMF_REQUIRE(l != nullptr, "%s: lists is null", what);
+    TMF_REQUIRE(l->n_users >= 0 && l->n_slices > 0 && l->n_samples > 0, "%s: n_users=%d n_slices=%d n_samples=%d", what,
+                l->n_users, l->n_slices, l->n_samples);
+    TMF_REQUIRE(l->n_users == 0 || (l->R_sorted && l->slice_off && l->rowptr && l->pos_off), "%s: null list array", what);
+    const int64_t groups = ((int64_t)l->n_users + kSliceUsers - 1) / kSliceUsers;
+    TMF_REQUIRE(groups * l->n_slices < ((int64_t)1 << 31), "%s: grid too large", what);
+    a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups};
     return TMF_OK;
 }
 
-template <typename T>
-static int wmrb_gradu2_impl(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices, int32_t n_users,
-                            int32_t S, const float* D, const void* V, float* part, int per_slice_launches,
-                            int n_components, void* stream) {
-    if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(R_sorted && slice_off && D && V && part && n_slices > 0 && S > 0, "wmrb_gradu2: bad arguments");
-    const RowGeom geom = row_geom_of<T>(n_components);
-    const int64_t groups = ((int64_t)n_users + kSliceUsers - 1) / kSliceUsers;
-    TMF_REQUIRE(groups * n_slices < ((int64_t)1 << 31), "wmrb_gradu2: grid too large");
-    const size_t lds = (size_t)(64 / (geom.G ? geom.G : 1)) * kWaves * 2 * 8 * geom.G * sizeof(int);
-    if (per_slice_launches) {
-        for (int sl = 0; sl < n_slices; ++sl) {
-#define CALL(G_, NV_)                                                                                          \
-    hipLaunchKernelGGL((k_wmrb_gradu2<G_, NV_, T>), dim3((unsigned)groups), dim3(kThreads), lds, (hipStream_t)stream, \
-                       R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups, (const T*)V, D, part, sl)
-            TMF_DISPATCH(T, geom, CALL);
-#undef CALL
-        }
-        return check_launch("tmf_wmrb_gradu2");
-    }
-#define CALL(G_, NV_)                                                                                           \
-    hipLaunchKernelGGL((k_wmrb_gradu2<G_, NV_, T>), dim3((unsigned)(groups * n_slices)), dim3(kThreads), lds,    \
-                       (hipStream_t)stream, R_sorted, slice_off, (int)n_slices, (int64_t)n_users, (int)S, groups,  \
-                       (const T*)V, D, part, -1)
-    TMF_DISPATCH(T, geom, CALL);
-#undef CALL
-    return check_launch("tmf_wmrb_gradu2");
+static size_t slice_lds(const RowGeom& geom) {
+    return (size_t)(64 / (geom.G ? geom.G : 1)) * kWaves * 2 * 8 * geom.G * sizeof(int);
 }
 
 template <typename T>
-static int wmrb_finish_impl(const float* gpos, const float* part, int32_t n_slices, int32_t n_users, const void* U_old,
-                            void* U_out, int n_components, int epi, tmf_adam adam, void* stream) {
+static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,
+                             int n_components, void* stream) {
+    SliceLists a;
+    if (int rc = check_lists(lists, a, "wmrb_scores3")) return rc;
+    if (a.n_users == 0) return TMF_OK;
+    TMF_REQUIRE(U && V && sp && (p || lists->col == nullptr), "wmrb_scores3: null pointer");
+    const RowGeom geom = row_geom_of<T>(n_components);
+    const size_t lds = slice_lds(geom);
+#define CALL(G_, NV_)                                                                                              \
+    hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.n_slices)), dim3(kThreads), lds, \
+                       (hipStream_t)stream, a, (const T*)U, (const T*)V, sp, p)
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_scores3");
+}
+
+template <typename T>
+static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const float* delta, const int32_t* ent_pos_smp,
+                            const int32_t* ent_pos_pos, float* w_ent, const void* V, float* part, int per_slice_launches,
+                            int n_components, void* stream) {
+    SliceLists a;
+    if (int rc = check_lists(lists, a, "wmrb_gradu3")) return rc;
+    if (a.n_users == 0) return TMF_OK;
+    TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
+    TMF_REQUIRE((ent_pos_smp == nullptr && ent_pos_pos == nullptr) || w_ent, "wmrb_gradu3: entry positions without w_ent");
+    const RowGeom geom = row_geom_of<T>(n_components);
+    const size_t lds = slice_lds(geom);
+    if (per_slice_launches) {
+        for (int sl = 0; sl < a.n_slices; ++sl) {
+#define CALL(G_, NV_)                                                                                                    \
+    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)a.n_groups), dim3(kThreads), lds, (hipStream_t)stream, a, \
+                       (const T*)V, D, delta, ent_pos_smp, ent_pos_pos, w_ent, part, sl)
+            TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+        }
+        return check_launch("tmf_wmrb_gradu3");
+    }
+#define CALL(G_, NV_)                                                                                             \
+    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.n_slices)), dim3(kThreads), lds, \
+                       (hipStream_t)stream, a, (const T*)V, D, delta, ent_pos_smp, ent_pos_pos, w_ent, part, -1)
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_gradu3");
+}
+
+template <typename T>
+static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,
+                            int n_components, int epi, tmf_adam adam, void* stream) {
     if (n_users == 0) return TMF_OK;
-    TMF_REQUIRE(gpos && part && U_out && n_slices > 0 && (epi == TMF_EPI_GRAD || U_old), "wmrb_finish: bad arguments");
+    TMF_REQUIRE(part && U_out && n_slices > 0 && (epi == TMF_EPI_GRAD || U_old), "wmrb_finish: bad arguments");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_finish: bad epilogue %d", epi);
     const RowGeom geom = row_geom_of<T>(n_components);
 #define CALL(G_, NV_)                                                                                                  \
     {                                                                                                                  \
         constexpr int per_block = (64 / G_) * kWaves;                                                                  \
         hipLaunchKernelGGL((k_wmrb_finish<G_, NV_, T>), dim3((unsigned)(((int64_t)n_users + per_block - 1) / per_block)), \
-                           dim3(kThreads), 0, (hipStream_t)stream, gpos, part, (int)n_slices, (int64_t)n_users,          \
+                           dim3(kThreads), 0, (hipStream_t)stream, part, (int)n_slices, (int64_t)n_users,                \
                            (const T*)U_old, U_out, epi, adam);                                                         \
     }
     TMF_DISPATCH(T, geom, CALL);
@@ -664,28 +664,20 @@ static int wmrb_finish_impl(const float* gpos, const float* part, int32_t n_slic
 }
 
 #define TMF_SLICED_ENTRY_POINTS(SFX, T_)                                                                                  \
-    extern "C" int tmf_wmrb_scores2_##SFX(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,             \
-                                          int32_t n_users, int32_t S, const void* U, const void* V, float* sp,            \
+    extern "C" int tmf_wmrb_scores3_##SFX(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p, \
                                           int n_components, void* stream) {                                               \
-        return wmrb_scores2_impl<T_>(R_sorted, slice_off, n_slices, n_users, S, U, V, sp, n_components, stream);           \
+        return wmrb_scores3_impl<T_>(lists, U, V, sp, p, n_components, stream);                                           \
     }                                                                                                                     \
-    extern "C" int tmf_wmrb_hinge_##SFX(const int64_t* rowptr, const int32_t* col, const float* val, const float* sp,     \
-                                        int32_t n_users, int32_t S, float c, const void* U_old, const void* V_old,        \
-                                        float* gpos, float* delta, float* D, float* loss_part, int n_components,          \
-                                        void* stream) {                                                                   \
-        return wmrb_hinge_impl<T_>(rowptr, col, val, sp, n_users, S, c, U_old, V_old, gpos, delta, D, loss_part,           \
-                                   n_components, stream);                                                                 \
-    }                                                                                                                     \
-    extern "C" int tmf_wmrb_gradu2_##SFX(const int32_t* R_sorted, const int32_t* slice_off, int32_t n_slices,              \
-                                         int32_t n_users, int32_t S, const float* D, const void* V, float* part,          \
-                                         int per_slice_launches, int n_components, void* stream) {                        \
-        return wmrb_gradu2_impl<T_>(R_sorted, slice_off, n_slices, n_users, S, D, V, part, per_slice_launches,            \
+    extern "C" int tmf_wmrb_gradu3_##SFX(const tmf_slice_lists* lists, const float* D, const float* delta,                \
+                                         const int32_t* ent_pos_smp, const int32_t* ent_pos_pos, float* w_ent,            \
+                                         const void* V, float* part, int per_slice_launches, int n_components,            \
+                                         void* stream) {                                                                  \
+        return wmrb_gradu3_impl<T_>(lists, D, delta, ent_pos_smp, ent_pos_pos, w_ent, V, part, per_slice_launches,        \
                                     n_components, stream);                                                                \
     }                                                                                                                     \
-    extern "C" int tmf_wmrb_finish_##SFX(const float* gpos, const float* part, int32_t n_slices, int32_t n_users,         \
-                                         const void* U_old, void* U_out, int n_components, int epi, tmf_adam adam,        \
-                                         void* stream) {                                                                  \
-        return wmrb_finish_impl<T_>(gpos, part, n_slices, n_users, U_old, U_out, n_components, epi, adam, stream);         \
+    extern "C" int tmf_wmrb_finish_##SFX(const float* part, int32_t n_slices, int32_t n_users, const void* U_old,         \
+                                         void* U_out, int n_components, int epi, tmf_adam adam, void* stream) {           \
+        return wmrb_finish_impl<T_>(part, n_slices, n_users, U_old, U_out, n_components, epi, adam, stream);               \
     }
 
 TMF_SLICED_ENTRY_POINTS(f32, float)

@@ -168,8 +168,7 @@ class MatrixFactorization:
         # epochs into one hipGraph and replay it - the per-launch host cost disappears from the loop.
         work = plan.nnz + (plan.n_users * wplan.S if wmrb else 0)
         G = min(epochs - epochs % 2, GRAPH_EPOCHS)
-        use_graph = (G >= 4 and work <= GRAPH_MAX_WORK and os.environ.get('TMF_NO_GRAPH') is None
-                     and not (wmrb and wplan.n_slices > 1))
+        use_graph = G >= 4 and work <= GRAPH_MAX_WORK and os.environ.get('TMF_NO_GRAPH') is None
         torch.cuda.synchronize(dev)
         t0 = timeit.default_timer()
         done = 0

@@ -28,12 +28,19 @@ def rel_err(x, ref):
     return float(np.abs(x - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-def close_with_slack(x, ref, slack=None, rtol=1e-5):
+def assert_close_with_slack(x, ref, slack=None, rtol=1e-5, what=''):
     """max_i (|x_i - ref_i| - slack_i) <= rtol * max|ref|: norm-wise agreement except for what the boundary hinge terms
     may legitimately move (oracle.sparse_ref.wmrb_slack / oracle_wmrb_boundary_slack)."""
     x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
-    d = np.abs(x - ref) - (0.0 if slack is None else 1.0001 * np.asarray(slack, np.float64))
-    return float(d.max()) <= rtol * max(float(np.abs(ref).max()), 1e-30) if d.size else True
+    if not x.size:
+        return
+    sl = np.zeros_like(ref) if slack is None else 1.0001 * np.asarray(slack, np.float64)
+    d = np.abs(x - ref) - sl
+    lim = rtol * max(float(np.abs(ref).max()), 1e-30)
+    if float(d.max()) > lim:
+        i = np.unravel_index(int(d.argmax()), d.shape)
+        raise AssertionError(f'{what}: {int((d > lim).sum())} of {d.size} elements differ by more than {lim:.3g} + slack; worst at {i}: '
+                             f'got {x[i]!r}, reference {ref[i]!r}, slack {sl[i]!r}')
 
 
 def step_bounds(W0, g_ref, lr, rtol=1e-5, slack=None):

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, rel_err, step_bounds
+from conftest import ROOT, assert_close_with_slack, rel_err, step_bounds
 
 pytestmark = pytest.mark.gpu
 
@@ -23,8 +23,8 @@ def _bf16_np(x):
     return torch.as_tensor(np.asarray(x, np.float32)).to(torch.bfloat16).to(torch.float32).numpy().astype(np.float64)
 
 
-def assert_step_bf16(W_new, W0, g_ref, lr, what=''):
-    lo, hi = step_bounds(W0, g_ref, lr)
+def assert_step_bf16(W_new, W0, g_ref, lr, what='', slack=None):
+    lo, hi = step_bounds(W0, g_ref, lr, slack=slack)
     W = np.asarray(W_new, np.float64)
     bad = (W < _bf16_np(lo) - 1e-12) | (W > _bf16_np(hi) + 1e-12)
     assert not bad.any(), f'{what}: {int(bad.sum())} of {bad.size} elements outside the bf16-rounded step interval'
@@ -42,8 +42,9 @@ def c5():
     m, n, r, S, lr = 1_250_000, 1_000_000, 256, 1024, 0.1
     idx, val = bench.gen_interactions(m, n, 125_000_000, 'zipf', 0, dev)
     g = torch.Generator(device=dev).manual_seed(3)
-    U0 = (torch.randn(m, r, device=dev, generator=g) * 0.08).to(torch.bfloat16)
-    V0 = (torch.randn(n, r, device=dev, generator=g) * 0.08).to(torch.bfloat16)
+    # scores ~ N(0, 1): about a fifth of the hinge terms are inactive, so every bucket of the hinge step is in use
+    U0 = (torch.randn(m, r, device=dev, generator=g) * 0.25).to(torch.bfloat16)
+    V0 = (torch.randn(n, r, device=dev, generator=g) * 0.25).to(torch.bfloat16)
     ld = _lib.padded_ld(r)   # the plans are sized like MatrixFactorization._fit_sparse sizes them
     plan = _engine.InteractionPlan(idx, val, m, n, csc=False)
     R = random_sampler_device(n, m, S, seed=100, device=dev)
@@ -76,18 +77,24 @@ def check_user(c5, u):
     U64 = c5['U0'][u:u + 1].float().cpu().numpy().astype(np.float64)
     Rc = inv[e - b:].cpu().numpy()[None]
     t = S.wmrb_terms(U64, Vc, idx, val, Rc, c5['n'], c5['S'])
-    assert rel_err(c5['D_model'][u].cpu().numpy(), t['D'][0]) < 1e-5, u
-    assert rel_err(w.delta[b:e].cpu().numpy(), t['delta']) < 1e-5, u
+    sl = S.wmrb_slack(U64, Vc, idx, val, Rc, c5['n'], c5['S'])   # what hinge terms sitting on the kink may move
+    assert_close_with_slack(c5['D_model'][u].cpu().numpy(), t['D'][0], sl['D'][0], what=f'D of user {u}')
+    assert_close_with_slack(w.delta[b:e].cpu().numpy(), t['delta'], sl['delta'], what=f'delta of user {u}')
     assert abs(float(st.loss_part[u]) - t['loss'].sum()) <= 1e-5 * t['loss'].sum(), u
     gU = (t['delta'][:, None] * Vc[idx[:, 1]]).sum(0) + t['D'][0] @ Vc[Rc[0]]
-    assert_step_bf16(st.U_nxt[u, :r].float().cpu().numpy()[None], U64, gU[None], c5['lr'], what=f'user {u}')
+    assert_step_bf16(st.U_nxt[u, :r].float().cpu().numpy()[None], U64, gU[None], c5['lr'], what=f'user {u}', slack=sl['gU'])
+    return t
 
 
 def test_c5_shard_sampled_users(c5):
     rng = np.random.default_rng(0)
     deg = (c5['plan'].rowptr_u[1:] - c5['plan'].rowptr_u[:-1]).cpu().numpy()
+    inactive = total = 0
     for u in list(rng.integers(0, c5['m'], 16)) + [int(deg.argmax()), int(deg.argmin())]:
-        check_user(c5, int(u))
+        t = check_user(c5, int(u))
+        inactive += int((t['cnt'] < c5['S']).sum())
+        total += len(t['cnt'])
+    assert inactive > 0.5 * total   # the sampled users really exercise partly inactive hinges
 
 
 def test_c5_shard_sampled_items_independent_entry_sets(c5):
@@ -100,7 +107,7 @@ def test_c5_shard_sampled_items_independent_entry_sets(c5):
         us = (c5['R'] == j).nonzero()
         g = (c5['D_model'][us[:, 0], us[:, 1]].to(torch.float64)[:, None] * st.U[us[:, 0], :r].to(torch.float64)).sum(0)
         k = ((plan.col_u == j) & (plan.val_u > 0)).nonzero().flatten()
-        g = g + (w.delta[k].to(torch.float64)[:, None] * st.U[plan.user_ids[k], :r].to(torch.float64)).sum(0)
+        g = g + (w.delta[k].to(torch.float64)[:, None] * st.U[plan.user_of[k].to(torch.int64), :r].to(torch.float64)).sum(0)
         assert int(us.shape[0] + k.numel()) == int(lens[j]), j
         assert_step_bf16(st.V_nxt[j, :r].float().cpu().numpy()[None], c5['V0'][j:j + 1].float().cpu().numpy(),
                          g.cpu().numpy()[None], c5['lr'], what=f'item {j} ({int(lens[j])} entries)')

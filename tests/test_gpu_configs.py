@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_step, close_with_slack, rel_err
+from conftest import assert_close_with_slack, assert_step, rel_err
 from test_gpu_parity import check_one_step, fit_model, tm  # noqa: F401  (tm is a fixture)
 
 pytestmark = pytest.mark.gpu
@@ -46,8 +46,9 @@ def test_c3_full_size(tm, S_):  # noqa: F811
     def check_step(model, Ub, Vb, mean, t, tag):
         sl = C.wmrb_boundary_slack(Ub, Vb, plan, n, S_)
         assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
-        assert close_with_slack(model._state.wplan.D_in_model_order().cpu().numpy(), t['D'], sl['D']), tag
-        assert close_with_slack(model._state.wplan.delta.cpu().numpy(), t['delta'], sl['delta']), tag  # a switch moves cnt_k by 1, delta_k by w_k
+        assert_close_with_slack(model._state.wplan.D_in_model_order().cpu().numpy(), t['D'], sl['D'], what=f'D {tag}')
+        # a switch moves cnt_k by 1, i.e. delta_k by w_k
+        assert_close_with_slack(model._state.wplan.delta.cpu().numpy(), t['delta'], sl['delta'], what=f'delta {tag}')
         assert_step(model.user_embedding.cpu().numpy(), Ub, t['gU'], lr, what=f'C3 U {tag}', slack=sl['gU'])
         assert_step(model.item_embedding.cpu().numpy(), Vb, t['gV'], lr, what=f'C3 V {tag}', slack=sl['gV'])
         return sl['pairs']

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, assert_step, rel_err
+from conftest import ROOT, assert_close_with_slack, assert_step, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,10 @@ def c4():
     dev = torch.device('cuda', 0)
     m, n, r, S, lr = 1_000_000, 100_000, 128, 1024, 0.1
     idx, val = bench.gen_interactions(m, n, 100_000_000, 'zipf', 0, dev)
-    U0, V0 = bench.init_table(m, r, 11, dev) * 300.0, bench.init_table(n, r, 7, dev) * 100.0  # O(0.3) entries
+    # entries ~ N(0, 0.3^2): scores ~ N(0, 1), so about a fifth of the hinge terms are inactive and every bucket of the
+    # hinge step (none / some / all positives active for a sample) is in use
+    U0 = bench.init_table(m, r, 11, dev) * (0.3 * (m * r) ** 0.5)
+    V0 = bench.init_table(n, r, 7, dev) * (0.3 * (n * r) ** 0.5)
     plan = _engine.InteractionPlan(idx, val, m, n)
     R = random_sampler_device(n, m, S, seed=100, device=dev)
     wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r), n_items=n),
@@ -59,13 +62,15 @@ def check_user_against_oracle(c4, u, V64=None):
     U64 = c4['U0'][u:u + 1].cpu().numpy().astype(np.float64)
     Rc = inv[e - b:].cpu().numpy()[None]
     t = S.wmrb_terms(U64, Vc, idx, val, Rc, c4['n'], c4['S'])
-    assert rel_err(c4['D_model'][u].cpu().numpy(), t['D'][0]) < 1e-5, u
+    sl = S.wmrb_slack(U64, Vc, idx, val, Rc, c4['n'], c4['S'])   # what hinge terms sitting on the kink may move
+    assert_close_with_slack(c4['D_model'][u].cpu().numpy(), t['D'][0], sl['D'][0], what=f'D of user {u}')
     pos = val > 0
-    assert rel_err(w.delta[b:e].cpu().numpy()[pos], t['delta']) < 1e-5, u
+    assert_close_with_slack(w.delta[b:e].cpu().numpy()[pos], t['delta'], sl['delta'], what=f'delta of user {u}')
     assert float(w.delta[b:e][~torch.as_tensor(pos, device=w.delta.device)].abs().sum()) == 0.0
     assert abs(float(st.loss_part[u]) - t['loss'].sum()) <= 1e-5 * t['loss'].sum(), u
     gU = (t['delta'][:, None] * Vc[idx[pos, 1]]).sum(0) + t['D'][0] @ Vc[Rc[0]]
-    assert_step(st.U_nxt[u, :c4['r']].cpu().numpy()[None], U64, gU[None], c4['lr'], what=f'user {u}')
+    assert_step(st.U_nxt[u, :c4['r']].cpu().numpy()[None], U64, gU[None], c4['lr'], what=f'user {u}', slack=sl['gU'])
+    return t
 
 
 def test_sampled_users_match_oracle(c4):
@@ -73,8 +78,12 @@ def test_sampled_users_match_oracle(c4):
     plan = c4['plan']
     deg = (plan.rowptr_u[1:] - plan.rowptr_u[:-1]).cpu().numpy()
     users = list(rng.integers(0, c4['m'], 24)) + [int(deg.argmax()), int(deg.argmin())]
+    inactive = total = 0
     for u in users:
-        check_user_against_oracle(c4, int(u))
+        t = check_user_against_oracle(c4, int(u))
+        inactive += int((t['cnt'] < c4['S']).sum())
+        total += len(t['cnt'])
+    assert inactive > 0.5 * total   # the sampled users really exercise partly inactive hinges
 
 
 def independent_item_gradient(j, R_model, D_model, plan, delta, U, r):
@@ -85,7 +94,7 @@ def independent_item_gradient(j, R_model, D_model, plan, delta, U, r):
     w_neg = D_model[us[:, 0], us[:, 1]].to(torch.float64)
     g = (w_neg[:, None] * U[us[:, 0], :r].to(torch.float64)).sum(0)
     k = ((plan.col_u == j) & (plan.val_u > 0)).nonzero().flatten()  # CSR positions of the item's positives
-    g = g + (delta[k].to(torch.float64)[:, None] * U[plan.user_ids[k], :r].to(torch.float64)).sum(0)
+    g = g + (delta[k].to(torch.float64)[:, None] * U[plan.user_of[k].to(torch.int64), :r].to(torch.float64)).sum(0)
     return g.cpu().numpy(), int(us.shape[0] + k.numel())
 
 
@@ -152,10 +161,10 @@ def test_full_size_mse_sampled_rows(c4):
         assert_step(st.V_nxt[j, :r].cpu().numpy()[None], st.V[j, :r].cpu().numpy()[None], g[None], c4['lr'], what=f'mse item {j}')
     # loss: fp64 recomputation over ALL interactions with torch (chunked)
     ref = 0.0
-    u_ids = plan.user_ids
+    u_ids = plan.user_of
     for b in range(0, plan.nnz, 1 << 24):
         e = min(b + (1 << 24), plan.nnz)
-        p = (st.U[u_ids[b:e], :r].to(torch.float64) * st.V[plan.col_u[b:e].to(torch.int64), :r].to(torch.float64)).sum(1)
+        p = (st.U[u_ids[b:e].to(torch.int64), :r].to(torch.float64) * st.V[plan.col_u[b:e].to(torch.int64), :r].to(torch.float64)).sum(1)
         ref += float(((plan.val_u[b:e].to(torch.float64) - p) ** 2).sum())
     assert abs(float(loss[0]) - ref) <= 1e-5 * ref
 

@@ -255,9 +255,10 @@ def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices):
 
 
 @pytest.mark.parametrize('forced_slices', [None, '3'])
-def test_wmrb_n_samples_beyond_lds_uses_global_workspace(tm, monkeypatch, forced_slices):
-    """S = 30000 negatives per user: 240 KB of scores + D per user do not fit the 160 KB of LDS.  Only the fused
-    pass has the global-workspace variant, so a catalog that would be sliced (here: forced) falls back to it."""
+def test_wmrb_n_samples_beyond_lds_takes_the_sliced_pass(tm, monkeypatch, forced_slices):
+    """S = 30000 negatives per user: 240 KB of scores + D per user do not fit the 160 KB of LDS the one-kernel user pass
+    needs, so the plan switches to the sliced pass (which has no limit on S) - with one slice for this small V table,
+    or with the forced number."""
     if forced_slices:
         monkeypatch.setenv('TMF_ITEM_SLICES', forced_slices)
     rng = np.random.default_rng(3)
@@ -269,8 +270,10 @@ def test_wmrb_n_samples_beyond_lds_uses_global_workspace(tm, monkeypatch, forced
     V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
     R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
     model, t = check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
-    assert model._state.user_ws is not None and model._state.wplan.n_slices == 1
-    assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
+    w = model._state.wplan
+    assert w.sliced and w.n_slices == (int(forced_slices) if forced_slices else 1)
+    assert not tm.engine.fused_user_pass_fits(S_, r) and tm.engine.fused_user_pass_fits(1024, 128)
+    assert rel_err(w.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
 
 
 def test_mse_user_blocked_item_pass(tm, golden, monkeypatch):
@@ -683,10 +686,14 @@ def test_native_index_prep_equals_torch_prep(tm):
             w = tm.engine.WmrbPlan(p, torch.tensor(R, device=dev), chunk=64, user_chunks=chunks, item_slices=3)
             plans.append((p, w))
         (pc, wc), (pg, wg) = plans
-        for name in ('rowptr_u', 'col_u', 'val_u', 'rowptr_i', 'row_i', 'val_i', 'user_ids'):
+        for name in ('rowptr_u', 'col_u', 'val_u', 'rowptr_i', 'row_i', 'val_i', 'user_of'):
             assert torch.equal(getattr(pc, name), getattr(pg, name).cpu()), (name, m, n, nnz)
-        for name in ('ent_row', 'ent_w', 'rowptr_e', 'R', 'slice_off'):
+        for name in ('ent_row', 'ent_pos', 'rowptr_e', 'R', 'slice_off', 'pos_off'):
             assert torch.equal(getattr(wc, name), getattr(wg, name).cpu()), (name, m, n, nnz)
+        wc1 = tm.engine.WmrbPlan(pc, torch.tensor(R), chunk=64, user_chunks=chunks)          # one-kernel user pass: ent_w
+        wg1 = tm.engine.WmrbPlan(pg, torch.tensor(R, device='cuda'), chunk=64, user_chunks=chunks)
+        for name in ('ent_row', 'ent_w', 'rowptr_e', 'R'):
+            assert torch.equal(getattr(wc1, name), getattr(wg1, name).cpu()), (name, m, n, nnz)
         for seg_c, seg_g in ((pc.seg_u, pg.seg_u), (pc.seg_i, pg.seg_i), (wc.seg_e, wg.seg_e)):
             for name in ('seg_row', 'seg_chunk', 'seg_slab', 'long_rows', 'long_slab_beg'):
                 assert torch.equal(getattr(seg_c, name), getattr(seg_g, name).cpu()), name
@@ -715,8 +722,14 @@ def test_c_abi_error_codes_and_messages(tm):
     assert rc == -1 and b'segments' in lib.tmf_last_error()
     rc = lib.tmf_adam_fresh_rows_f32(tm.lib.ptr(x), tm.lib.ptr(x), 8, 5000, adam, s)              # rank out of range
     assert rc == -1
-    assert lib.tmf_padded_ld(5000) == 0 and lib.tmf_wmrb_user_workspace_bytes(10, 100, 8) == 0
-    assert lib.tmf_wmrb_user_workspace_bytes(10, 40000, 8) == 10 * 40000 * 4
+    assert lib.tmf_padded_ld(5000) == 0 and lib.tmf_wmrb_user_pass_fits(100, 8) == 1
+    assert lib.tmf_wmrb_user_pass_fits(40000, 8) == 0 and lib.tmf_wmrb_user_pass_fits(100, 5000) == 0
+    d = torch.zeros(8, 40000, device='cuda')
+    rp = torch.zeros(9, dtype=torch.int64, device='cuda')
+    Ri = torch.zeros(8, 40000, dtype=torch.int32, device='cuda')
+    rc = lib.tmf_wmrb_user_pass_f32(tm.lib.ptr(rp), None, None, tm.lib.ptr(Ri), 8, 40000, 1.0, tm.lib.ptr(x), tm.lib.ptr(x),
+                                    tm.lib.ptr(x), None, tm.lib.ptr(d), None, None, 8, 0, adam, s)
+    assert rc == -3 and b'sliced' in lib.tmf_last_error()                                         # scores do not fit LDS
     with pytest.raises(tm.lib.EngineError):
         tm.lib.check(rc, lib)
     torch.cuda.synchronize()

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tmf_version() == 100
+    assert lib.tmf_version() == 200
 
 
 def test_padded_ld_and_adam_constants_match_host_mirror():
@@ -62,7 +62,7 @@ def test_segment_table_and_plans_against_numpy():
     idx = np.stack([rng.integers(0, m, 120), rng.integers(0, n, 120)], axis=1)
     val = rng.integers(-1, 4, 120).astype(np.float32)
     plan = InteractionPlan(torch.tensor(idx), torch.tensor(val), m, n, chunk=chunk)
-    order = np.argsort(idx[:, 0], kind='stable')
+    order = np.argsort(idx[:, 0] * n + idx[:, 1], kind='stable')   # row-major, duplicates in input order
     u, j, v = idx[order, 0], idx[order, 1], val[order]
     assert np.array_equal(plan.col_u.numpy(), j) and np.array_equal(plan.val_u.numpy(), v)
     assert np.array_equal(plan.rowptr_u.numpy(), np.concatenate([[0], np.cumsum(np.bincount(u, minlength=m))]))
@@ -100,7 +100,9 @@ def test_segment_table_and_plans_against_numpy():
     # WMRB entry lists: per item, positives (ascending user) then (user, slot) pairs
     R = np.stack([rng.choice(n, S, replace=False) for _ in range(m)]).astype(np.int32)
     w = WmrbPlan(plan, torch.tensor(R), chunk=chunk)
+    assert not w.sliced and w.ent_pos is None
     rpe = w.rowptr_e.numpy()
+    assert len(rpe) == n + 1 and rpe[-1] == (v > 0).sum() + m * S    # stored values <= 0 are in no list
     for item in range(n):
         rows = w.ent_row.numpy()[rpe[item]:rpe[item + 1]]
         ws = w.ent_w.numpy()[rpe[item]:rpe[item + 1]]
@@ -109,6 +111,17 @@ def test_segment_table_and_plans_against_numpy():
         assert list(ws) == list(pos_k) + list(len(v) + us * S + ss)
         assert list(rows) == list(u[pos_k]) + list(us)
     assert w.delta.numel() == len(v) and tuple(w.D.shape) == (m, S)
+    # the sliced pass stores the weights at their list positions instead: ent_pos is the inverse of ent_w
+    ws_ = WmrbPlan(plan, torch.tensor(R), chunk=chunk, item_slices=2)
+    assert ws_.sliced and ws_.ent_w is None and np.array_equal(ws_.rowptr_e.numpy(), rpe)
+    Rs = np.sort(R, axis=1)
+    for item in range(n):
+        pos_k = np.nonzero((j == item) & (v > 0))[0]
+        us, ss = np.nonzero(Rs == item)
+        ids = list(pos_k) + list(len(v) + us * S + ss)
+        assert list(ws_.ent_pos.numpy()[ids]) == list(range(rpe[item], rpe[item + 1]))
+        assert list(ws_.ent_row.numpy()[rpe[item]:rpe[item + 1]]) == list(u[pos_k]) + list(us)
+    assert (ws_.ent_pos.numpy()[np.nonzero(v <= 0)[0]] >= rpe[-1]).all()
     # user-chunked lists: list row = block * n + item; per item the union over blocks is the same entry set,
     # every segment owns a slab slot and the slots of an item are consecutive
     C = 3
@@ -189,13 +202,17 @@ def test_item_slices_and_defaults_on_cpu(monkeypatch):
     w = WmrbPlan(plan, torch.tensor(R), user_chunks=2, item_slices=NS)
     Rs = w.R.numpy()
     assert np.array_equal(Rs, np.sort(R, axis=1))                      # negatives kept sorted by item
-    assert np.array_equal(np.take_along_axis(R, w.sample_perm.numpy(), 1), Rs)
     width = -(-n // NS)
-    off = w.slice_off.numpy()
+    off, poff = w.slice_off.numpy(), w.pos_off.numpy()
     assert off.shape == (m, NS + 1) and (off[:, 0] == 0).all() and (off[:, -1] == S).all()
+    rp, col = plan.rowptr_u.numpy(), plan.col_u.numpy()
+    assert poff.shape == (m, NS + 1) and (poff[:, 0] == 0).all() and np.array_equal(poff[:, -1], np.diff(rp))
     for u in range(m):
+        assert (np.diff(col[rp[u]:rp[u + 1]]) >= 0).all()              # interactions of a user: ascending item
         for sl in range(NS):
             seg = Rs[u, off[u, sl]:off[u, sl + 1]]
+            assert ((seg >= sl * width) & (seg < (sl + 1) * width)).all()
+            seg = col[rp[u] + poff[u, sl]:rp[u] + poff[u, sl + 1]]
             assert ((seg >= sl * width) & (seg < (sl + 1) * width)).all()
     # D written in sorted order maps back to the model's order
     w.D.copy_(torch.tensor(Rs.astype(np.float32)))                      # pretend D[u, s] = item id of the sorted slot
