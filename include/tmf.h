@@ -105,8 +105,8 @@ int tmf_stable_order_i32(const int32_t* keys, int64_t n, int64_t n_rows, int64_t
  *     + item, blocks of ceil(n_users / user_chunks) users): every list holds the item's positives (ascending CSR
  *     position) followed by the (user, sample) pairs whose negative is the item.  Entry ids: i < nnz = interaction i of
  *     the CSR, nnz + u * S + s = negative s of user u (R_sorted order).  Outputs, E = nnz + n_users * S (< 2^31):
- *       ent_row [E] user of every list entry; ent_id [E] (optional) entry id of every list entry; ent_pos [E] (optional)
- *       position of every entry id in the lists (stored values <= 0 sit in a dummy list row behind all others);
+ *       ent_row [E] user of every list entry; ent_id [E] entry id of every list entry (= its index into the weight
+ *       buffer [delta | D] of tmf_wsum_pass; stored values <= 0 sit in a dummy list row behind all others);
  *       rowptr_e [user_chunks * n_items + 2]. */
 size_t tmf_sort_samples_workspace_bytes(int32_t n_users, int32_t n_samples);
 int tmf_sort_samples(const int32_t* R, int32_t n_users, int32_t n_samples, int32_t n_items, int32_t* R_sorted,
@@ -116,8 +116,8 @@ int tmf_slice_offsets(const int32_t* ids, const int64_t* rowptr, int64_t stride,
 size_t tmf_wmrb_entry_lists_workspace_bytes(int64_t nnz, int32_t n_users, int32_t n_samples);
 int tmf_wmrb_entry_lists(const int32_t* user_of, const int32_t* col_u, const float* val_u, int64_t nnz,
                          const int32_t* R_sorted, int32_t n_users, int32_t n_samples, int32_t n_items, int32_t user_chunks,
-                         int32_t* ent_row, int32_t* ent_id, int32_t* ent_pos, int64_t* rowptr_e, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         int32_t* ent_row, int32_t* ent_id, int64_t* rowptr_e, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* K1+K2 / K3: one side of an MSE epoch (loss_graphs.py:47-52 forward; tape.gradient
  * matrix_factorization.py:170-171; Adam :176) evaluated sparsely:
@@ -130,9 +130,8 @@ int tmf_mse_pass_f32(const tmf_segments* seg, const int32_t* other, const float*
                      float* loss_part, int n_components, int epi, tmf_adam adam, void* stream);
 
 /* Weighted row-gather-sum pass (item side of WMRB, matrix_factorization.py:170-171 through
- * loss_graphs.py:80-88):  g[i] = sum over entries e of row i of  w_e * T[ent_row[e]]  with w_e = wbuf[ent_w[e]], or
- * w_e = wbuf[e] when ent_w is NULL (weights already stored in entry order, as tmf_wmrb_gradu3 leaves them); entries
- * with weight exactly 0 are skipped; then the epilogue writes X_out[i]. */
+ * loss_graphs.py:80-88):  g[i] = sum over entries e of row i of  wbuf[ent_w[e]] * T[ent_row[e]]
+ * (entries with weight exactly 0 are skipped), then the epilogue writes X_out[i]. */
 int tmf_wsum_pass_f32(const tmf_segments* seg, const int32_t* ent_row, const int32_t* ent_w,
                       const float* wbuf, const float* T, const float* X_old, float* X_out,
                       float* slab, int n_components, int epi, tmf_adam adam, void* stream);
@@ -174,9 +173,6 @@ typedef struct tmf_slice_lists {
  *   tmf_wmrb_scores3_*  sp[u, s] = <U[u], V[R_sorted[u, s]]>, p[k] = <U[u_k], V[col[k]]>         (slice-major grid)
  *   tmf_wmrb_hinge2     delta [nnz], D [n_users, n_samples] (R_sorted order), loss_part [n_users]; reads no table
  *   tmf_wmrb_gradu3_*   part[slice][u] = sum_{s in slice} D[u, s] V[R_sorted[u, s]] + sum_{k in slice} delta_k V[col[k]]
- *                       and, when ent_pos_* are given, w_ent[ent_pos_smp[u * S + s]] = D[u, s],
- *                       w_ent[ent_pos_pos[k]] = delta_k (the weights of tmf_wsum_pass in entry order; negative
- *                       positions are skipped)
  *                       per_slice_launches = 0: one launch, part is [n_slices * n_users, ld], finish gets n_slices;
  *                       per_slice_launches = 1: one launch per slice adding into ONE [n_users, ld] layer (memory-light;
  *                       finish is then called with n_slices = 1)
@@ -187,12 +183,10 @@ int tmf_wmrb_scores3_bf16(const tmf_slice_lists* lists, const void* U, const voi
                           int n_components, void* stream);
 int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
                     int32_t n_samples, float c, float* delta, float* D, float* loss_part, void* stream);
-int tmf_wmrb_gradu3_f32(const tmf_slice_lists* lists, const float* D, const float* delta, const int32_t* ent_pos_smp,
-                        const int32_t* ent_pos_pos, float* w_ent, const void* V, float* part, int per_slice_launches,
-                        int n_components, void* stream);
-int tmf_wmrb_gradu3_bf16(const tmf_slice_lists* lists, const float* D, const float* delta, const int32_t* ent_pos_smp,
-                         const int32_t* ent_pos_pos, float* w_ent, const void* V, float* part, int per_slice_launches,
-                         int n_components, void* stream);
+int tmf_wmrb_gradu3_f32(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, float* part,
+                        int per_slice_launches, int n_components, void* stream);
+int tmf_wmrb_gradu3_bf16(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, float* part,
+                         int per_slice_launches, int n_components, void* stream);
 int tmf_wmrb_finish_f32(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,
                         int n_components, int epi, tmf_adam adam, void* stream);
 int tmf_wmrb_finish_bf16(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,

@@ -220,10 +220,9 @@ class WmrbPlan:
     negative is the item; list row = block * n_items + item, blocks of ceil(n_users / user_chunks) users outermost, so
     the waves running at any moment gather U rows of ONE cache-sized block of users.  Entry ids: k < nnz = interaction k
     of the CSR, nnz + u * S + s = negative s of user u; ``ent_row[e]`` = user of list entry e.
-    Weights: ``wbuf = [delta (nnz) | D (m * S)]`` indexed by entry id.  The fused user pass writes it and the item pass
-    gathers through ``ent_w`` (entry id of every list entry); the sliced user pass (``sliced``) additionally stores
-    every weight at its list position (``ent_pos``: entry id -> list position, ``w_ent``), which the item pass streams.
-    Sliced pass: ``R`` holds every user's negatives in ascending item order, ``slice_off`` / ``pos_off`` the first
+    Weights: ``wbuf = [delta (nnz) | D (m * S)]`` indexed by entry id; the user pass writes it and the item pass gathers
+    through ``ent_w`` (entry id of every list entry).
+    Sliced pass (``sliced``): ``R`` holds every user's negatives in ascending item order, ``slice_off`` / ``pos_off`` the first
     negative / interaction of every item slice."""
 
     def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128):
@@ -271,15 +270,13 @@ class WmrbPlan:
         self.R = R.contiguous()
         # ---- item-side entry lists ----
         self.ent_row = torch.empty(E, dtype=torch.int32, device=dev)
-        self.ent_w = self.ent_pos = None
         rowptr = torch.empty(C * n + 2, dtype=torch.int64, device=dev)
         if native:
-            ent_id = None if self.sliced else torch.empty(E, dtype=torch.int32, device=dev)
-            ent_pos = torch.empty(E, dtype=torch.int32, device=dev) if self.sliced else None
+            ent_id = torch.empty(E, dtype=torch.int32, device=dev)
             ws = torch.empty(lib.tmf_wmrb_entry_lists_workspace_bytes(nnz, m, S), dtype=torch.uint8, device=dev)
             _lib.check(lib.tmf_wmrb_entry_lists(_lib.ptr(plan.user_of), _lib.ptr(plan.col_u), _lib.ptr(plan.val_u), nnz,
                                                 _lib.ptr(self.R), i32(m), i32(S), i32(n), i32(C), _lib.ptr(self.ent_row),
-                                                _lib.ptr(ent_id), _lib.ptr(ent_pos), _lib.ptr(rowptr), _lib.ptr(ws), ws.numel(),
+                                                _lib.ptr(ent_id), _lib.ptr(rowptr), _lib.ptr(ws), ws.numel(),
                                                 _lib.stream_ptr()), lib)
             del ws
         else:
@@ -292,15 +289,9 @@ class WmrbPlan:
             rowptr = _excl_cumsum(torch.bincount(keys, minlength=C * n + 1))
             owner = torch.cat([ku, torch.arange(m, dtype=torch.int64).repeat_interleave(S)])  # user of every entry id
             self.ent_row = owner[ent_id].to(torch.int32)
-            ent_pos = torch.empty(E, dtype=torch.int32)
-            ent_pos[ent_id] = torch.arange(E, dtype=torch.int32)
             ent_id = ent_id.to(torch.int32)
         self.rowptr_e = rowptr[:C * n + 1].contiguous()  # the row behind them holds the stored values <= 0: never read
-        if self.sliced:
-            self.ent_pos = ent_pos
-            self.w_ent = torch.zeros(E, dtype=torch.float32, device=dev)
-        else:
-            self.ent_w = ent_id
+        self.ent_w = ent_id
         if C > 1:
             out_row = torch.arange(C * n, device=dev) % n
             self.seg_e = SegmentTable(self.rowptr_e, chunk, out_row=out_row, n_out=n)
@@ -440,10 +431,8 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None):
                                                                             _lib.ptr(st.pk), r, s))
     timed('wmrb_hinge', lambda: lib.tmf_wmrb_hinge2(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(st.pk), _lib.ptr(st.sp),
                                                     i32(m), i32(S), c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), s))
-    nnz = p.nnz
     timed('wmrb_gradu', lambda: getattr(lib, 'tmf_wmrb_gradu3' + st.sfx)(
-        lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(w.ent_pos[nnz:]), _lib.ptr(w.ent_pos[:nnz]), _lib.ptr(w.w_ent),
-        _lib.ptr(st.V), _lib.ptr(st.part), int(st.part_layers == 1 and ns > 1), r, s))
+        lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(st.V), _lib.ptr(st.part), int(st.part_layers == 1 and ns > 1), r, s))
     timed('wmrb_finish', lambda: getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.part), i32(st.part_layers), i32(m),
                                                                           _lib.ptr(st.U), _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s))
 
@@ -467,8 +456,7 @@ def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, pro
     V_out = st.V_nxt if item_out is None else item_out
     if prof:
         prof.start('wmrb_item_pass')
-    weights, ent_w = (w.w_ent, None) if w.sliced else (w.wbuf, w.ent_w)   # entry order (streamed) or gathered through ent_w
-    _lib.check(getattr(lib, 'tmf_wsum_pass' + st.sfx)(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(ent_w), _lib.ptr(weights),
+    _lib.check(getattr(lib, 'tmf_wsum_pass' + st.sfx)(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf),
                                      _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(V_out), _lib.ptr(st.slab), r, item_epi,
                                      adam, s), lib)
     if prof:

@@ -63,7 +63,7 @@ _BASE_SIGNATURES = {
     'tmf_sort_samples': (_I, [_P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     'tmf_slice_offsets': (_I, [_P, _P, _L, _I32, _I32, _I32, _P, _P]),
     'tmf_wmrb_entry_lists_workspace_bytes': (_SZ, [_L, _I32, _I32]),
-    'tmf_wmrb_entry_lists': (_I, [_P, _P, _P, _L, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
+    'tmf_wmrb_entry_lists': (_I, [_P, _P, _P, _L, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
     'tmf_mse_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
@@ -71,7 +71,7 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_user_pass_fits': (_I, [_I32, _I]),
     'tmf_wmrb_scores3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_hinge2': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P]),
-    'tmf_wmrb_gradu3_f32': (_I, [_SL, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'tmf_wmrb_gradu3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _I, _P]),
     'tmf_wmrb_finish_f32': (_I, [_P, _I32, _I32, _P, _P, _I, _I, Adam, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
     'tmf_mse_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),

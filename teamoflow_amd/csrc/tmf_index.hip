@@ -95,15 +95,12 @@ __global__ __launch_bounds__(256) void k_entry_keys(const int32_t* __restrict__ 
     }
 }
 
-// After the sort: the user of every list entry, and for every entry id its position in the lists.
+// After the sort: the user of every list entry.
 __global__ __launch_bounds__(256) void k_entry_rows(const int32_t* __restrict__ order, const int32_t* __restrict__ user_of,
-                                                    int64_t nnz, int64_t S, int64_t total, int32_t* __restrict__ ent_row,
-                                                    int32_t* __restrict__ ent_id, int32_t* __restrict__ ent_pos) {
+                                                    int64_t nnz, int64_t S, int64_t total, int32_t* __restrict__ ent_row) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t id = order[e];
         ent_row[e] = (id < nnz) ? user_of[id] : (int32_t)((id - nnz) / S);
-        if (ent_id) ent_id[e] = (int32_t)id;
-        if (ent_pos) ent_pos[id] = (int32_t)e;
     }
 }
 
@@ -260,16 +257,16 @@ extern "C" int tmf_slice_offsets(const int32_t* ids, const int64_t* rowptr, int6
     return check_launch("tmf_slice_offsets");
 }
 
-// workspace: [keys_in E*4][keys_out E*4][ids E*4][order E*4][rocprim temp],  E = nnz + n_users * S
+// workspace: [keys_in E*4][keys_out E*4][ids E*4][rocprim temp],  E = nnz + n_users * S (the sorted ids land in ent_id)
 extern "C" size_t tmf_wmrb_entry_lists_workspace_bytes(int64_t nnz, int32_t n_users, int32_t S) {
     const int64_t E = nnz + (int64_t)n_users * S;
     const int64_t n = E > 0 ? E : 1;
-    return 4 * align256((size_t)n * 4) + align256(sort_temp_bytes_v32(n));
+    return 3 * align256((size_t)n * 4) + align256(sort_temp_bytes_v32(n));
 }
 
 extern "C" int tmf_wmrb_entry_lists(const int32_t* user_of, const int32_t* col_u, const float* val_u, int64_t nnz,
                                     const int32_t* R_sorted, int32_t n_users, int32_t S, int32_t n_items, int32_t user_chunks,
-                                    int32_t* ent_row, int32_t* ent_id, int32_t* ent_pos, int64_t* rowptr_e, void* workspace,
+                                    int32_t* ent_row, int32_t* ent_id, int64_t* rowptr_e, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     const int64_t E = nnz + (int64_t)n_users * S;
     TMF_REQUIRE(nnz >= 0 && n_users >= 0 && S >= 0 && n_items > 0 && user_chunks > 0 && rowptr_e, "entry_lists: bad arguments");
@@ -283,7 +280,7 @@ extern "C" int tmf_wmrb_entry_lists(const int32_t* user_of, const int32_t* col_u
                            rowptr_e);
         return check_launch("tmf_wmrb_entry_lists");
     }
-    TMF_REQUIRE(ent_row && (nnz == 0 || (user_of && col_u && val_u)) && ((int64_t)n_users * S == 0 || R_sorted),
+    TMF_REQUIRE(ent_row && ent_id && (nnz == 0 || (user_of && col_u && val_u)) && ((int64_t)n_users * S == 0 || R_sorted),
                 "entry_lists: null pointer");
     TMF_REQUIRE(workspace && workspace_bytes >= tmf_wmrb_entry_lists_workspace_bytes(nnz, n_users, S), "entry_lists: workspace too small");
     char* w = static_cast<char*>(workspace);
@@ -291,8 +288,8 @@ extern "C" int tmf_wmrb_entry_lists(const int32_t* user_of, const int32_t* col_u
     int32_t* keys_in = reinterpret_cast<int32_t*>(w);
     int32_t* keys_out = reinterpret_cast<int32_t*>(w + a4);
     int32_t* ids = reinterpret_cast<int32_t*>(w + 2 * a4);
-    int32_t* order = reinterpret_cast<int32_t*>(w + 3 * a4);
-    void* temp = w + 4 * a4;
+    int32_t* order = ent_id;
+    void* temp = w + 3 * a4;
     size_t temp_bytes = sort_temp_bytes_v32(E);
     const int64_t upb = ((int64_t)n_users + user_chunks - 1) / user_chunks;
     hipLaunchKernelGGL(k_entry_keys, dim3(grid_for(E)), dim3(256), 0, s, user_of, col_u, val_u, nnz, R_sorted, (int64_t)n_users,
@@ -300,7 +297,6 @@ extern "C" int tmf_wmrb_entry_lists(const int32_t* user_of, const int32_t* col_u
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, ids, order, (size_t)E, 0, bits_for(n_rows + 1), s);
     if (e != hipSuccess) { set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return TMF_E_LAUNCH; }
     hipLaunchKernelGGL(k_rowptr, dim3(grid_for(n_rows + 2)), dim3(256), 0, s, (const int32_t*)keys_out, E, n_rows + 1, rowptr_e);
-    hipLaunchKernelGGL(k_entry_rows, dim3(grid_for(E)), dim3(256), 0, s, (const int32_t*)order, user_of, nnz, (int64_t)S, E, ent_row,
-                       ent_id, ent_pos);
+    hipLaunchKernelGGL(k_entry_rows, dim3(grid_for(E)), dim3(256), 0, s, (const int32_t*)order, user_of, nnz, (int64_t)S, E, ent_row);
     return check_launch("tmf_wmrb_entry_lists");
 }

@@ -3,6 +3,7 @@
 // fresh-Adam row update and the deterministic loss sum.  See include/tmf.h for the contracts
 // and DESIGN.md for the bytes each kernel moves.
 #include <type_traits>
+
 #include "tmf_common.h"
 
 namespace tmf {
@@ -91,14 +92,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weighted gather-sum pass: g[row] = sum_e w_e * T[ent_row[e]] with w_e = wbuf[ent_w[e]] (GATHERW: weights looked up
-// through an index) or w_e = wbuf[e] (weights already in entry order - the sliced user pass stores them that way).
-// Each wave stages a tile of its segment's entries (row id + weight) in LDS first, so that the row gathers depend on
-// an LDS read only - the chain entry -> weight -> row would otherwise be three dependent global reads.
+// Weighted gather-sum pass: g[row] = sum_e wbuf[ent_w[e]] * T[ent_row[e]].  Each wave stages a tile of
+// its segment's entries (row id + gathered weight) in LDS first, so that the row gathers depend on an LDS
+// read only - the chain entry -> weight -> row would otherwise be three dependent global reads.
+// (Giving every XCD a contiguous eighth of the segments - a user block of its own, so that the 4-byte weight gathers of
+// neighbouring lists are served by ONE L2 - changed nothing: 32.8 vs 32.6 ms at C4, profiles/r02_hinge_rewrite.txt.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kWsumTile = 512;  // entries a wave stages in LDS per step (ids + weights: 4 KB per wave)
 
-template <int G, int NV, typename T, bool GATHERW>
+template <int G, int NV, typename T>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
     SegView sv, const int32_t* __restrict__ ent_row, const int32_t* __restrict__ ent_w,
     const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
         // the wave stages the tile: coalesced entry reads, all weight gathers in flight together
         for (int e = lane; e < cnt; e += 64) {
             ids[e] = ent_row[t0 + e];
-            ws[e] = GATHERW ? wbuf[ent_w[t0 + e]] : wbuf[t0 + e];
+            ws[e] = wbuf[ent_w[t0 + e]];
         }
         // lane group `grp` takes entries grp, grp + NG, ...; a row is only loaded when its weight is not 0
         for (int e0 = grp; e0 < cnt; e0 += NG * kUnroll) {
@@ -273,18 +275,14 @@ static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const
                           tmf_adam adam, void* stream) {
     if (int rc = check_segments(seg)) return rc;
     if (seg->nseg == 0) return TMF_OK;
-    TMF_REQUIRE(Tab && X_out && ent_row && wbuf && (epi == TMF_EPI_GRAD || X_old), "wsum_pass: null pointer");
+    TMF_REQUIRE(Tab && X_out && ent_row && ent_w && wbuf && (epi == TMF_EPI_GRAD || X_old), "wsum_pass: null pointer");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wsum_pass: bad epilogue %d", epi);
     const RowGeom geom = row_geom_of<T>(n_components);
     const SegView sv = view(seg);
     const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
-#define CALL(G_, NV_)                                                                                                    \
-    if (ent_w != nullptr)                                                                                                \
-        hipLaunchKernelGGL((k_wsum_pass<G_, NV_, T, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
-                           sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam);               \
-    else                                                                                                                 \
-        hipLaunchKernelGGL((k_wsum_pass<G_, NV_, T, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
-                           sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
+#define CALL(G_, NV_)                                                                                           \
+    hipLaunchKernelGGL((k_wsum_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
     TMF_DISPATCH(T, geom, CALL);
 #undef CALL
     return check_launch("tmf_wsum_pass");

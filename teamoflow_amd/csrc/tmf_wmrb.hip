@@ -359,9 +359,10 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 //   k_wmrb_scores3   sp[u, s] = <U[u], V[R[u, s]]> for the negatives in the slice, p[k] = <U[u], V[j_k]> for the
 //                    user's interactions in the slice                                             -> global
 //   k_wmrb_hinge2    (tmf_hinge.hip) sp, p -> delta, D, loss; touches no table
-//   k_wmrb_gradu3    part[slice][u] = sum_{s in slice} D[u, s] V[R[u, s]] + sum_{k in slice} delta_k V[j_k]; on the
-//                    way every weight is also stored at its position in the item-side entry lists (w_ent), so the
-//                    item pass streams its weights instead of gathering them 4 bytes at a time
+//   k_wmrb_gradu3    part[slice][u] = sum_{s in slice} D[u, s] V[R[u, s]] + sum_{k in slice} delta_k V[j_k]
+//                    (storing every weight at its position in the item-side entry lists on the way, so that the item
+//                    pass could stream them, was measured: the 4-byte scatter cost this kernel +36 ms and saved the
+//                    item pass 8 ms - writes from different XCDs do not merge; profiles/r02_hinge_rewrite.txt)
 //   k_wmrb_finish    gU[u] = sum_slice part[slice][u] (fixed order) -> epilogue
 // Block placement is used for speed only; any dispatch order gives the same bits.
 // Both slice roles stage the ids (and weights) of a (user, slice) range through LDS so that a row gather
@@ -383,26 +384,17 @@ __device__ __forceinline__ int* slice_stage(char* smem_raw, int gid) {
 
 // One list (the negatives or the interactions of a user that fall into the slice): entries [beg, end) of `list`.
 //   GRADU = false: out[t] = <x, V[list[t]]>
-//   GRADU = true : acc += wts[t] V[list[t]] (rows with weight 0 are not loaded); w_ent[entpos[t]] = wts[t] when
-//                  entpos is given and entpos[t] >= 0
+//   GRADU = true : acc += wts[t] V[list[t]] (rows with weight 0 are not loaded)
 template <int G, int NV, typename T, bool GRADU>
 __device__ __forceinline__ void slice_list(int* ids, float* dst, const int32_t* __restrict__ list, int beg, int end,
                                            const T* __restrict__ V, const Frag<NV>& x, Frag<NV>& acc,
-                                           float* __restrict__ out, const float* __restrict__ wts,
-                                           const int32_t* __restrict__ entpos, float* __restrict__ w_ent, int g) {
+                                           float* __restrict__ out, const float* __restrict__ wts, int g) {
     constexpr int kStageTile = Stage<G>::tile;
     for (int t0 = beg; t0 < end; t0 += kStageTile) {
         const int cnt = (end - t0 < kStageTile) ? end - t0 : kStageTile;
         for (int e = g; e < cnt; e += G) {
             ids[e] = list[t0 + e];
-            if (GRADU) {
-                const float w = wts[t0 + e];
-                dst[e] = w;
-                if (entpos != nullptr) {
-                    const int ep = entpos[t0 + e];
-                    if (ep >= 0) w_ent[ep] = w;
-                }
-            }
+            if (GRADU) dst[e] = wts[t0 + e];
         }
         float keep = 0.f;  // scores: lane g keeps the score of entry (e & (G-1)) == g until G of them are complete
         for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
@@ -473,10 +465,9 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T
         if (nb == ne && pb == pe) continue;
         Frag<NV> x, none;
         load_row<G, NV>(x, U, u, g);
-        slice_list<G, NV, T, false>(ids, dst, a.R + u * (int64_t)a.S, nb, ne, V, x, none, sp + u * (int64_t)a.S, nullptr,
-                                    nullptr, nullptr, g);
+        slice_list<G, NV, T, false>(ids, dst, a.R + u * (int64_t)a.S, nb, ne, V, x, none, sp + u * (int64_t)a.S, nullptr, g);
         const int64_t rb = a.rowptr[u];
-        slice_list<G, NV, T, false>(ids, dst, a.col + rb, pb, pe, V, x, none, p + rb, nullptr, nullptr, nullptr, g);
+        slice_list<G, NV, T, false>(ids, dst, a.col + rb, pb, pe, V, x, none, p + rb, nullptr, g);
     }
 }
 
@@ -484,9 +475,8 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T
 // (plain read-modify-write; launches of consecutive slices are ordered by the stream).
 template <int G, int NV, typename T>
 __global__ __launch_bounds__(kThreads) void k_wmrb_gradu3(SliceLists a, const T* __restrict__ V, const float* __restrict__ D,
-                                                          const float* __restrict__ delta, const int32_t* __restrict__ eps,
-                                                          const int32_t* __restrict__ epp, float* __restrict__ w_ent,
-                                                          float* __restrict__ part, int slice_first) {
+                                                          const float* __restrict__ delta, float* __restrict__ part,
+                                                          int slice_first) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NG = 64 / G, NGB = NG * kWaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -503,9 +493,8 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_gradu3(SliceLists a, const T*
         Frag<NV> acc, none;
         zero<NV>(acc);
         const int64_t us = u * (int64_t)a.S, rb = a.rowptr[u];
-        slice_list<G, NV, T, true>(ids, dst, a.R + us, nb, ne, V, none, acc, nullptr, D + us, eps ? eps + us : nullptr, w_ent, g);
-        slice_list<G, NV, T, true>(ids, dst, a.col + rb, pb, pe, V, none, acc, nullptr, delta + rb, epp ? epp + rb : nullptr,
-                                   w_ent, g);
+        slice_list<G, NV, T, true>(ids, dst, a.R + us, nb, ne, V, none, acc, nullptr, D + us, g);
+        slice_list<G, NV, T, true>(ids, dst, a.col + rb, pb, pe, V, none, acc, nullptr, delta + rb, g);
         if (accumulate == 0) {
             store_row_f32<G, NV, T>(acc, part, sl * a.n_users + u, g);
         } else {  // one launch per slice: part is a single [users, ld] layer summed in slice order
@@ -616,21 +605,19 @@ static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const 
 }
 
 template <typename T>
-static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const float* delta, const int32_t* ent_pos_smp,
-                            const int32_t* ent_pos_pos, float* w_ent, const void* V, float* part, int per_slice_launches,
-                            int n_components, void* stream) {
+static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, float* part,
+                            int per_slice_launches, int n_components, void* stream) {
     SliceLists a;
     if (int rc = check_lists(lists, a, "wmrb_gradu3")) return rc;
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
-    TMF_REQUIRE((ent_pos_smp == nullptr && ent_pos_pos == nullptr) || w_ent, "wmrb_gradu3: entry positions without w_ent");
     const RowGeom geom = row_geom_of<T>(n_components);
     const size_t lds = slice_lds(geom);
     if (per_slice_launches) {
         for (int sl = 0; sl < a.n_slices; ++sl) {
 #define CALL(G_, NV_)                                                                                                    \
     hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)a.n_groups), dim3(kThreads), lds, (hipStream_t)stream, a, \
-                       (const T*)V, D, delta, ent_pos_smp, ent_pos_pos, w_ent, part, sl)
+                       (const T*)V, D, delta, part, sl)
             TMF_DISPATCH(T, geom, CALL);
 #undef CALL
         }
@@ -638,7 +625,7 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
     }
 #define CALL(G_, NV_)                                                                                             \
     hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.n_slices)), dim3(kThreads), lds, \
-                       (hipStream_t)stream, a, (const T*)V, D, delta, ent_pos_smp, ent_pos_pos, w_ent, part, -1)
+                       (hipStream_t)stream, a, (const T*)V, D, delta, part, -1)
     TMF_DISPATCH(T, geom, CALL);
 #undef CALL
     return check_launch("tmf_wmrb_gradu3");
@@ -669,11 +656,9 @@ static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users
         return wmrb_scores3_impl<T_>(lists, U, V, sp, p, n_components, stream);                                           \
     }                                                                                                                     \
     extern "C" int tmf_wmrb_gradu3_##SFX(const tmf_slice_lists* lists, const float* D, const float* delta,                \
-                                         const int32_t* ent_pos_smp, const int32_t* ent_pos_pos, float* w_ent,            \
                                          const void* V, float* part, int per_slice_launches, int n_components,            \
                                          void* stream) {                                                                  \
-        return wmrb_gradu3_impl<T_>(lists, D, delta, ent_pos_smp, ent_pos_pos, w_ent, V, part, per_slice_launches,        \
-                                    n_components, stream);                                                                \
+        return wmrb_gradu3_impl<T_>(lists, D, delta, V, part, per_slice_launches, n_components, stream);                  \
     }                                                                                                                     \
     extern "C" int tmf_wmrb_finish_##SFX(const float* part, int32_t n_slices, int32_t n_users, const void* U_old,         \
                                          void* U_out, int n_components, int epi, tmf_adam adam, void* stream) {           \

@@ -688,7 +688,7 @@ def test_native_index_prep_equals_torch_prep(tm):
         (pc, wc), (pg, wg) = plans
         for name in ('rowptr_u', 'col_u', 'val_u', 'rowptr_i', 'row_i', 'val_i', 'user_of'):
             assert torch.equal(getattr(pc, name), getattr(pg, name).cpu()), (name, m, n, nnz)
-        for name in ('ent_row', 'ent_pos', 'rowptr_e', 'R', 'slice_off', 'pos_off'):
+        for name in ('ent_row', 'ent_w', 'rowptr_e', 'R', 'slice_off', 'pos_off'):
             assert torch.equal(getattr(wc, name), getattr(wg, name).cpu()), (name, m, n, nnz)
         wc1 = tm.engine.WmrbPlan(pc, torch.tensor(R), chunk=64, user_chunks=chunks)          # one-kernel user pass: ent_w
         wg1 = tm.engine.WmrbPlan(pg, torch.tensor(R, device='cuda'), chunk=64, user_chunks=chunks)

@@ -100,7 +100,7 @@ def test_segment_table_and_plans_against_numpy():
     # WMRB entry lists: per item, positives (ascending user) then (user, slot) pairs
     R = np.stack([rng.choice(n, S, replace=False) for _ in range(m)]).astype(np.int32)
     w = WmrbPlan(plan, torch.tensor(R), chunk=chunk)
-    assert not w.sliced and w.ent_pos is None
+    assert not w.sliced
     rpe = w.rowptr_e.numpy()
     assert len(rpe) == n + 1 and rpe[-1] == (v > 0).sum() + m * S    # stored values <= 0 are in no list
     for item in range(n):
@@ -111,17 +111,15 @@ def test_segment_table_and_plans_against_numpy():
         assert list(ws) == list(pos_k) + list(len(v) + us * S + ss)
         assert list(rows) == list(u[pos_k]) + list(us)
     assert w.delta.numel() == len(v) and tuple(w.D.shape) == (m, S)
-    # the sliced pass stores the weights at their list positions instead: ent_pos is the inverse of ent_w
+    # the sliced pass keeps every user's negatives sorted by item: same lists, entry ids of the sorted slots
     ws_ = WmrbPlan(plan, torch.tensor(R), chunk=chunk, item_slices=2)
-    assert ws_.sliced and ws_.ent_w is None and np.array_equal(ws_.rowptr_e.numpy(), rpe)
+    assert ws_.sliced and np.array_equal(ws_.rowptr_e.numpy(), rpe)
     Rs = np.sort(R, axis=1)
     for item in range(n):
         pos_k = np.nonzero((j == item) & (v > 0))[0]
         us, ss = np.nonzero(Rs == item)
-        ids = list(pos_k) + list(len(v) + us * S + ss)
-        assert list(ws_.ent_pos.numpy()[ids]) == list(range(rpe[item], rpe[item + 1]))
+        assert list(ws_.ent_w.numpy()[rpe[item]:rpe[item + 1]]) == list(pos_k) + list(len(v) + us * S + ss)
         assert list(ws_.ent_row.numpy()[rpe[item]:rpe[item + 1]]) == list(u[pos_k]) + list(us)
-    assert (ws_.ent_pos.numpy()[np.nonzero(v <= 0)[0]] >= rpe[-1]).all()
     # user-chunked lists: list row = block * n + item; per item the union over blocks is the same entry set,
     # every segment owns a slab slot and the slots of an item are consecutive
     C = 3
