@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the matrix-factorization training hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full-batch training epoch (user pass + item pass + fresh-Adam updates + loss), the
 unit the reference times at matrix_factorization.py:129-177.  Workload = BASELINE.json's metric
 configuration: 1M users x 100K items, r = 128, WMRB with S = 1024 static negatives, ~1e8 interactions
-("C4"), fp32, synthetic data generated on the device.  With N > 1 every rank holds its
-own 1M users (weak scaling), V is replicated and its gradient is exchanged by RCCL reduce-scatter /
-all-gather (teamoflow_amd/dist.py).  Rank 0 prints ONE JSON line.
+("C4"), fp32, synthetic data generated on the device.  With N > 1 the users are split over
+the ranks, V is replicated and its gradient is exchanged by RCCL reduce-scatter / all-gather
+(teamoflow_amd/dist.py): `--scaling weak` gives every rank its own 1M users, `--scaling strong` splits the
+ONE 1M-user problem (BASELINE config 4 as written) into contiguous cost-balanced user blocks.
+Rank 0 prints ONE JSON line; DESIGN.md §4 defines every field of its `roofline` object.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,7 +30,9 @@ from teamoflow_amd import _engine, _lib, _ops  # noqa: E402
 from teamoflow_amd import dist as tdist  # noqa: E402
 from teamoflow_amd.mf.utils import random_sampler_device  # noqa: E402
 
-HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; per-XCD L2 aggregate ~34.5 TB/s; Infinity Cache 256 MiB
+HBM_PEAK, L2_PEAK, MALL_BYTES = 8.0e12, 34.5e12, 256 << 20
+L2_GATHER_MEASURED = (16.8e12, 18.8e12)  # the guide's measured chip-wide rate of L2-resident row gathers
 
 
 def log(*a):
@@ -71,15 +76,149 @@ def init_table(rows, r, seed, dev):
     return x * torch.rsqrt(torch.clamp((x * x).sum(), min=1e-12))
 
 
-def wmrb_bytes(m, n, S, P, r, s=4):
-    """Algorithmic bytes per epoch split by kernel."""
-    user = m * S * (2 * r * s + 8) + P * (r * s + 12) + m * 2 * r * s
-    item = m * S * (r * s + 8) + P * (r * s + 12) + n * 2 * r * s
-    return user, item
+# ---------------------------------------------------------------------------------------------
+# Byte models.  Per kernel:
+#   gather  = bytes of factor rows the kernel pulls into registers, every gathered row counted (what the
+#             L2 / Infinity Cache / HBM hierarchy has to deliver to the CUs) - SURVEY §8d's "algorithmic" figure;
+#   hbm     = bytes that have to cross the HBM interface at least once: every streamed array once, a factor table
+#             (or the cache-sized window the kernel is blocked into) once per sweep when it is cache-resident
+#             (<= 256 MiB Infinity Cache), every gathered row when it is not.
+# ---------------------------------------------------------------------------------------------
+def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, part_layers=None):
+    row = ld * s          # bytes of one factor row as stored
+    row32 = ld * 4        # fp32 partial / gradient rows
+    U_tab, V_tab = m * row, n * row
+    v_resident = V_tab <= MALL_BYTES or ns > 1   # sliced: the slice being walked is L2-resident
+    k = {}
+    if sliced:
+        off = 2 * m * (ns + 1) * 4
+        layers = ns if part_layers is None else part_layers
+        # gradU partial rows: one fp32 layer per slice written once, or (memory-light) ONE layer read-modified-written per slice
+        part_wr = ns * m * row32 if layers == ns else (2 * ns - 1) * m * row32
+        k['wmrb_scores'] = dict(rows=m * S + nnz, gather=(m * S + nnz) * row,
+                                hbm=m * S * 4 + off + nnz * 4 + U_tab + (V_tab if v_resident else (m * S + nnz) * row) + m * S * 4 + nnz * 4,
+                                roof='l2' if v_resident else 'hbm',
+                                what='sampled + interaction scores: V rows gathered from the L2-resident slice, ids staged in LDS')
+        k['wmrb_hinge'] = dict(rows=0, gather=0, hbm=m * S * 4 + 2 * nnz * 4 + m * 8 + m * S * 4 + nnz * 4, roof='issue',
+                               what='sort + binary search + scans per user (one wave per user); streams sp / p in, D / delta out')
+        k['wmrb_gradu'] = dict(rows=m * S + nnz, gather=(m * S + nnz) * row,
+                               hbm=2 * m * S * 4 + off + 2 * nnz * 4 + (V_tab if v_resident else (m * S + nnz) * row) + part_wr,
+                               roof='l2' if v_resident else 'hbm',
+                               what='D- and delta-weighted V rows per (user, slice); rows with weight 0 are skipped (but counted here)')
+        k['wmrb_finish'] = dict(rows=0, gather=0, hbm=layers * m * row32 + 2 * U_tab, roof='hbm', what='ordered sum of the slice partials + fresh Adam')
+    else:
+        k['wmrb_user_pass'] = dict(rows=2 * (m * S + nnz), gather=2 * (m * S + nnz) * row,
+                                   hbm=m * S * 4 + 2 * nnz * 4 + 2 * U_tab + (V_tab if V_tab <= MALL_BYTES else 2 * (m * S + nnz) * row) + m * S * 4 + nnz * 4,
+                                   roof='l2' if V_tab <= MALL_BYTES else 'hbm', what='fused user pass (one workgroup per user)')
+    u_resident = U_tab <= MALL_BYTES or C > 1   # user-blocked lists: the block being gathered from is L2-resident
+    k['wmrb_item_pass'] = dict(rows=E_lists, gather=E_lists * row,
+                               hbm=E_lists * 12 + (U_tab if u_resident else E_lists * row) + (n_slab * row32 if n_slab else 2 * V_tab),
+                               roof='l2' if u_resident else 'hbm',
+                               what='weighted U-row gather-sum over the (user block, item) lists; 4-byte weight gathers')
+    if n_slab:
+        k['wmrb_combine'] = dict(rows=0, gather=0, hbm=n_slab * row32 + 2 * V_tab, roof='hbm', what='ordered sum of the per-block partial rows + fresh Adam')
+    return k
 
 
-def mse_bytes(m, n, nnz, r, s=4):
-    return nnz * (r * s + 12) + m * 2 * r * s, nnz * (r * s + 12) + n * 2 * r * s
+def mse_kernel_models(m, n, nnz, ld, s):
+    row = ld * s
+    U_tab, V_tab = m * row, n * row
+    k = {}
+    # the gathered table is either cache-resident (Infinity Cache: priced against the L2 roof, the upper bound of anything
+    # served on chip) or streams from HBM row by row
+    k['mse_user_pass'] = dict(rows=nnz, gather=nnz * row, hbm=nnz * 8 + 2 * U_tab + (V_tab if V_tab <= MALL_BYTES else nnz * row),
+                              roof='l2' if V_tab <= MALL_BYTES else 'hbm', what='gather V rows -> dot -> loss -> gradient -> Adam, CSR by user')
+    k['mse_item_pass'] = dict(rows=nnz, gather=nnz * row, hbm=nnz * 8 + 2 * V_tab + (U_tab if U_tab <= MALL_BYTES else nnz * row),
+                              roof='l2' if U_tab <= MALL_BYTES else 'hbm', what='the same with U rows, CSC by item')
+    return k
+
+
+def roofline_report(models, prof, pmc=None):
+    """One entry per kernel: its measured duration (HIP events on the launch stream inside the timed region), the rate
+    it moves its gather bytes at against the L2 roof, its compulsory HBM bytes against the HBM roof, and - when a
+    PMC profile of this code version is committed - the measured fabric traffic.  No entry carries a fraction > 1."""
+    entries = []
+    for name, k in models.items():
+        ms = prof.mean_ms(name)
+        if not ms == ms:   # NaN: kernel not launched
+            continue
+        t = ms * 1e-3
+        e = dict(kernel=name, ms=ms, what=k['what'], hbm_bytes=k['hbm'], hbm_rate_GBps=k['hbm'] / t / 1e9,
+                 hbm_frac=k['hbm'] / t / HBM_PEAK)
+        if k['gather']:
+            e.update(rows_gathered=k['rows'], gather_bytes=k['gather'], gather_rate_GBps=k['gather'] / t / 1e9,
+                     l2_frac=k['gather'] / t / L2_PEAK)
+        if k['roof'] == 'l2':
+            e.update(bound='l2', achieved=e['gather_rate_GBps'], peak=L2_PEAK / 1e9, frac=e['l2_frac'])
+        elif k['roof'] == 'hbm':
+            e.update(bound='hbm', achieved=e['hbm_rate_GBps'], peak=HBM_PEAK / 1e9, frac=e['hbm_frac'])
+        else:
+            e.update(bound='issue', achieved=e['hbm_rate_GBps'], peak=HBM_PEAK / 1e9, frac=e['hbm_frac'],
+                     note='instruction-issue / LDS-latency bound; the HBM figure only shows it is far from that roof')
+        if pmc and name in pmc:
+            e.update(traffic=pmc[name]['bytes'], hbm_traffic_frac=pmc[name]['bytes'] / t / HBM_PEAK,
+                     traffic_uncorrected=pmc[name]['bytes_uncorrected'])
+        entries.append(e)
+    entries.sort(key=lambda e: -e['ms'])
+    return entries
+
+
+# kernel symbol prefixes of the per-kernel timer names, for matching the committed PMC profile
+PMC_KERNELS = {'wmrb_scores': 'tmf::k_wmrb_scores3', 'wmrb_hinge': 'tmf::k_wmrb_hinge2', 'wmrb_gradu': 'tmf::k_wmrb_gradu3',
+               'wmrb_finish': 'tmf::k_wmrb_finish', 'wmrb_item_pass': 'tmf::k_wsum_pass', 'wmrb_combine': 'tmf::k_combine_rows',
+               'wmrb_user_pass': 'tmf::k_wmrb_user'}
+PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_c4_latest.json')
+
+
+def csrc_sha():
+    """Fingerprint of the kernel sources a PMC profile belongs to (tools/profile_summary.py stamps the same value)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'teamoflow_amd', 'csrc')
+    files = sorted(f for f in os.listdir(d) if f.endswith(('.hip', '.h')))
+    for path in [os.path.join(d, f) for f in files] + [os.path.join(ROOT, 'include', 'tmf.h')]:
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """Fabric bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and WRITE_SIZE
+    in separate runs).  bench.py cannot collect counters itself; the workload is seeded, so the profile applies to this
+    run - but only when it was taken on THIS version of the kernels: the file carries the sha of csrc/ and is ignored on
+    a mismatch.  FETCH_SIZE counts half the bytes of 16-byte-per-lane reads on gfx950 (MI355X_MICROARCH.md, HBM):
+    `bytes` doubles it for the row-gather kernels (their traffic is 16-byte row loads), `bytes_uncorrected` does not."""
+    try:
+        d = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None, 'no profile committed'
+    if d.get('_csrc_sha') != csrc_sha():
+        return None, f"profile is for csrc {d.get('_csrc_sha')}, this is {csrc_sha()}"
+    out = {}
+    for name, prefix in PMC_KERNELS.items():
+        for k, v in d.items():
+            if k.startswith(prefix) and 'FETCH_SIZE_KB_mean_per_launch' in v:
+                f, w = v['FETCH_SIZE_KB_mean_per_launch'] * 1024, v.get('WRITE_SIZE_KB_mean_per_launch', 0) * 1024
+                wide = name != 'wmrb_hinge'   # the hinge kernel reads 4 bytes per lane: correction not calibrated, left out
+                out[name] = dict(bytes=(2 * f if wide else f) + w, bytes_uncorrected=f + w)
+    return out, os.path.relpath(PMC_FILE, ROOT)
+
+
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box
+    shows all 256 host CPUs but grants a 16-core share; spinning up 256 OpenMP threads there stalls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, 16) if n > 64 else n
 
 
 def cpu_baseline(loss, idx, val, R, U0, V0, n, S, lr, users=None, epochs=3):
@@ -123,42 +262,6 @@ def recall_parity(dev):
     got = float(model.recall_at_k(torch.tensor(g['A'])).mean())
     want = float(dense_ref.recall_at_k_dense(g['U_450'], g['V_450'], g['A'], 10).mean())
     return got, want
-
-
-PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_c4_latest.json')
-PMC_KERNELS = {'wmrb_user_pass': 'tmf::k_wmrb_user<32, 1, float, false, false>',
-               'wmrb_item_pass': 'tmf::k_wsum_pass<32, 1, float>'}
-
-
-def pmc_traffic(kname):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-    command (FETCH_SIZE and WRITE_SIZE in separate runs, bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, the
-    gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect counters itself; the workload is
-    seeded, so the profile applies to this run.  None when no profile is committed."""
-    try:
-        d = json.load(open(PMC_FILE))
-        return float(d[PMC_KERNELS[kname]]['hbm_traffic_bytes_per_launch_corrected']), os.path.relpath(PMC_FILE, ROOT)
-    except (OSError, KeyError, ValueError):
-        return None, None
-
-
-def host_cores():
-    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box
-    shows all 256 host CPUs but grants a 16-core share; spinning up 256 OpenMP threads there stalls)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        try:
-            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
-            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except (OSError, ValueError):
-            pass
-    return min(n, 16) if n > 64 else n
 
 
 def small_configs(dev, quick=False):
@@ -231,11 +334,143 @@ def small_configs(dev, quick=False):
     return out
 
 
+class Workload:
+    """One rank's problem, resident in HBM: interactions, negative table, plans, factor tables."""
+
+    def __init__(self, args, m, n, nnz_target, r, S, loss, dtype, rank, world, dev, strong=False):
+        self.n, self.r, self.S, self.loss, self.dtype = n, r, S, loss, dtype
+        t0 = time.perf_counter()
+        n_pad = tdist.padded_rows(n, world)
+        if strong and world > 1:
+            # the ONE global problem, cut into contiguous user blocks of balanced cost (interactions + negatives)
+            idx, val = gen_interactions(m, n, nnz_target, args.item_dist, 0, dev)
+            deg = torch.bincount(idx[:, 0], minlength=m)
+            bounds = tdist.partition_users(_engine._excl_cumsum(deg), world, per_user_cost=S if loss == 'wmrb' else 0)
+            b, e = bounds[rank], bounds[rank + 1]
+            keep = (idx[:, 0] >= b) & (idx[:, 0] < e)
+            idx, val = idx[keep].clone(), val[keep].clone()
+            idx[:, 0] -= b
+            U0 = init_table(m, r, 11, dev)[b:e].clone()
+            self.user_block, m = (b, e), e - b
+        else:
+            idx, val = gen_interactions(m, n, nnz_target, args.item_dist, rank, dev)
+            U0 = init_table(m, r, 11 + rank, dev)
+            self.user_block = (rank * m, (rank + 1) * m)
+        self.m = m
+        self.idx, self.val, self.nnz = idx, val, int(val.numel())
+        V0 = torch.zeros(n_pad, r, device=dev)
+        V0[:n] = init_table(n, r, 7, dev)  # identical on every rank
+        self.U0, self.V0, self.n_pad = U0, V0, n_pad
+        ld = _lib.padded_ld(r)
+        self.plan = _engine.InteractionPlan(idx, val, m, n_pad, user_chunks=_engine.mse_user_chunks() if loss == 'mse' else 1,
+                                            csc=loss == 'mse')
+        self.wplan, self.R = None, None
+        if loss == 'wmrb':
+            self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
+            self.wplan = _engine.WmrbPlan(self.plan, self.R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n),
+                                          item_slices=_engine.default_item_slices(n, ld), n_components=r)
+        self.st = _engine.TrainState(U0, V0, self.plan, r, self.wplan, dtype=torch.bfloat16 if dtype == 'bf16' else torch.float32)
+        self.adam = _engine.adam_constants(args.lr)
+        self.c = n / S
+        torch.cuda.synchronize()
+        self.prep_seconds = time.perf_counter() - t0
+
+    def models(self):
+        st, p, w = self.st, self.plan, self.wplan
+        s = 2 if self.dtype == 'bf16' else 4
+        if self.loss == 'wmrb':
+            return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced,
+                                      int(w.rowptr_e[-1]), w.seg_e.n_slab, w.user_chunks,
+                                      getattr(st, 'part_layers', None))
+        return mse_kernel_models(self.m, self.n, self.nnz, st.ld, s)
+
+    def describe(self, tag):
+        return (f'{tag}: {self.m} users x {self.n} items per GPU, r={self.r}, {self.loss.upper()}'
+                + (f' S={self.S}' if self.loss == 'wmrb' else '') + ', item ids zipf-like, lognormal user degrees')
+
+
+def run_steps(wl, steps, warmup, dp=None, backend=None):
+    """W untimed + K timed epochs -> (seconds of the K epochs, seconds of the W epochs, KernelTimer, loss buffer)."""
+    st, prof = wl.st, _engine.KernelTimer()
+    loss_buf = torch.zeros(steps + warmup + 1, dtype=torch.float64, device=st.U.device)
+
+    def step(i, p):
+        if dp is not None:
+            backend.prof = p
+            loss_buf[i] = dp.step()
+        else:
+            if wl.loss == 'wmrb':
+                _engine.epoch_wmrb(st, wl.adam, wl.c, loss_buf[i:i + 1], prof=p)
+            else:
+                _engine.epoch_mse(st, wl.adam, loss_buf[i:i + 1], prof=p)
+            st.swap()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dp is not None:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    tw = time.perf_counter()
+    for i in range(warmup):
+        step(i, None)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i, prof)
+    fence()
+    t1 = time.perf_counter()
+    return t1 - t0, t0 - tw, prof, loss_buf
+
+
+def hbm_leg(args, dev, name, m, n, nnz, r, S, loss, dtype, steps, warmup):
+    """A side leg on a workload whose factor tables really stream from HBM: same timed-region rules."""
+    wl = Workload(args, m, n, nnz, r, S, loss, dtype, 0, 1, dev)
+    elapsed, _, prof, loss_buf = run_steps(wl, steps, warmup)
+    models = wl.models()
+    out = dict(workload=wl.describe(name), interactions=wl.nnz, steps=steps, warmup=warmup, ms_per_step=elapsed / steps * 1e3,
+               value=wl.nnz / (elapsed / steps), unit='interactions/s', dtype='f32' if dtype == 'f32' else 'bf16 storage / f32 arithmetic',
+               kernels=roofline_report(models, prof), prep_seconds=wl.prep_seconds,
+               epoch_hbm_bytes=sum(k['hbm'] for k in models.values()),
+               epoch_hbm_frac=sum(k['hbm'] for k in models.values()) / (elapsed / steps) / HBM_PEAK,
+               hbm_gib_peak=torch.cuda.max_memory_allocated() / 2 ** 30)
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def api_fit(dev, wl, args, epochs):
+    """The same workload through the PUBLIC class surface: MatrixFactorization(...).fit(epochs) - plan build and epoch loop
+    timed by the model itself (plan_seconds_, fit_seconds_)."""
+    from teamoflow_amd.mf.initializer_graphs import FixedInitializer
+    from teamoflow_amd.mf.loss_graphs import MSELoss, WMRBLoss
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    from teamoflow_amd.mf.sparse import SparseInteractions, eye
+    kw = dict(user_weight_graph=FixedInitializer(wl.U0), item_weight_graph=FixedInitializer(wl.V0[:wl.n]))
+    if wl.loss == 'wmrb':
+        kw.update(loss_graph=WMRBLoss(), n_users=wl.m, n_items=wl.n, n_samples=wl.S)
+    else:
+        kw.update(loss_graph=MSELoss())
+    model = MatrixFactorization(wl.r, **kw)
+    model.verbose = False
+    if wl.loss == 'wmrb':
+        model.random_ind = wl.R
+    model.fit(epochs, eye(wl.m), eye(wl.n), SparseInteractions(wl.idx, wl.val, (wl.m, wl.n)), lr=args.lr)
+    out = dict(epochs=epochs, plan_seconds=model.plan_seconds_, epoch_loop_seconds=model.fit_seconds_,
+               ms_per_epoch=model.fit_seconds_ / epochs * 1e3, loss_first_last=[model.loss_history_[0], model.loss_history_[-1]])
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='N > 1: weak = every rank its own --users users; strong = the one --users problem split over the ranks')
     ap.add_argument('--users', type=int, default=1_000_000)
     ap.add_argument('--items', type=int, default=100_000)
     ap.add_argument('--rank', type=int, default=128, dest='r')
@@ -245,8 +480,9 @@ def main():
     ap.add_argument('--item-dist', choices=['zipf', 'uniform'], default='zipf')
     ap.add_argument('--lr', type=float, default=0.1)
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32', help='factor storage (arithmetic is fp32 either way)')
-    ap.add_argument('--small-configs', action='store_true', help='also time BASELINE configs 1-3 (GPU fit vs dense CPU restatement)')
-    ap.add_argument('--no-extras', action='store_true', help='skip cpu baseline / predict / mse side measurements')
+    ap.add_argument('--small-configs', action='store_true', help='time BASELINE configs 1-3 in full (GPU fit vs dense CPU restatement)')
+    ap.add_argument('--no-extras', action='store_true', help='skip cpu baseline / predict / API / HBM legs / small configs')
+    ap.add_argument('--no-legs', action='store_true', help='skip the two HBM-streaming side legs (C4 MSE, config-5 shard)')
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner at communicator
@@ -278,126 +514,79 @@ def main():
             torch.distributed.init_process_group('gloo')
         else:
             torch.distributed.init_process_group('nccl', device_id=dev)
-    red_dev = 'cpu' if rehearse else dev   # where the two scalar reductions of the report live
+    red_dev = 'cpu' if rehearse else dev   # where the scalar reductions of the report live
     _lib.get()
 
-    m, n, r, S = args.users, args.items, args.r, args.samples
-    t_prep = time.perf_counter()
-    idx, val = gen_interactions(m, n, args.nnz, args.item_dist, rank, dev)
-    nnz = int(val.numel())
-    n_pad = tdist.padded_rows(n, world)
-    U0 = init_table(m, r, 11 + rank, dev)
-    V0 = torch.zeros(n_pad, r, device=dev)
-    V0[:n] = init_table(n, r, 7, dev)  # identical on every rank
-    plan = _engine.InteractionPlan(idx, val, m, n_pad, user_chunks=_engine.mse_user_chunks() if args.loss == 'mse' else 1,
-                                   csc=args.loss == 'mse')
-    wplan, R = None, None
-    if args.loss == 'wmrb':
-        R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
-        wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, _lib.padded_ld(r), n_items=n),
-                                 item_slices=_engine.default_item_slices(n, _lib.padded_ld(r)), n_components=r)
-    tdtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    sbytes = 2 if args.dtype == 'bf16' else 4
-    st = _engine.TrainState(U0, V0, plan, r, wplan, dtype=tdtype)
-    adam = _engine.adam_constants(args.lr)
-    c = n / S
-    torch.cuda.synchronize()
+    strong = args.scaling == 'strong'
+    wl = Workload(args, args.users, args.items, args.nnz, args.r, args.samples, args.loss, args.dtype, rank, world, dev, strong)
     if rank == 0:
-        log(f'[bench] prepared {nnz} interactions, m={m} n={n} r={r} S={S} in {time.perf_counter() - t_prep:.1f} s; '
+        log(f'[bench] prepared {wl.nnz} interactions, m={wl.m} n={wl.n} r={wl.r} S={wl.S} in {wl.prep_seconds:.1f} s; '
             f'{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak')
-
-    prof = _engine.KernelTimer()
-    loss_buf = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
+    dp = backend = None
     if dp_mode:
-        backend = tdist.HipBackend(st, args.loss, c, adam, prof=None)
-        dp = tdist.DataParallelEpoch(backend, plan.n_pos if args.loss == 'wmrb' else nnz)
-
-    def step(i, p):
-        if dp_mode:
-            backend.prof = p
-            loss_buf[i] = dp.step()
-        else:
-            if args.loss == 'wmrb':
-                _engine.epoch_wmrb(st, adam, c, loss_buf[i:i + 1], prof=p)
-            else:
-                _engine.epoch_mse(st, adam, loss_buf[i:i + 1], prof=p)
-            st.swap()
-
-    def fence():
-        torch.cuda.synchronize()
-        if dp_mode:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i, None)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, prof)
-    fence()
-    elapsed = time.perf_counter() - t0
+        backend = tdist.HipBackend(wl.st, args.loss, wl.c, wl.adam, prof=None)
+        dp = tdist.DataParallelEpoch(backend, wl.plan.n_pos if args.loss == 'wmrb' else wl.nnz)
+    elapsed, warm_elapsed, prof, loss_buf = run_steps(wl, args.steps, args.warmup, dp, backend)
+    comm = None
     if dp_mode:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-        tot = torch.tensor([float(nnz)], dtype=torch.float64, device=red_dev)
+        tot = torch.tensor([float(wl.nnz)], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(tot)
         nnz_total = float(tot)
+        comm = dp.comm_report()
     else:
-        nnz_total = float(nnz)
+        nnz_total = float(wl.nnz)
     ms_per_step = elapsed / args.steps * 1e3
 
-    # dominant kernel + roofline (HIP events on the launch stream, inside the timed region)
-    if args.loss == 'wmrb':
-        ub, ib = wmrb_bytes(m, n, S, plan.n_pos, r, sbytes)
-        ums, ims = prof.mean_ms('wmrb_user_pass'), prof.mean_ms('wmrb_item_pass')
-        sliced = wplan.sliced
-        # dominant single kernel: the fused user pass, or (sliced user pass = 4 kernels) the item gather-sum
-        if not sliced and ums >= ims:
-            kname, kbytes, kms = 'wmrb_user_pass', ub, ums
-        else:
-            kname, kbytes, kms = 'wmrb_item_pass', ib, ims
-        other = {'wmrb_user_pass_ms': ums, 'wmrb_user_pass_alg_bytes': ub, 'wmrb_item_pass_ms': ims,
-                 'wmrb_item_pass_alg_bytes': ib,
-                 'wmrb_user_pass_form': (f'sliced: scores + hinge + gradU + finish kernels over {wplan.n_slices} item slices'
-                                         if sliced else 'fused single kernel'),
-                 'wmrb_item_lists_user_blocks': wplan.user_chunks}
-    else:
-        ub, ib = mse_bytes(m, n, nnz, r, sbytes)
-        kname, kbytes = 'mse_item_pass', ib
-        kms = prof.mean_ms('mse_item_pass')
-        other = {'mse_user_pass_ms': prof.mean_ms('mse_user_pass'), 'mse_user_pass_alg_bytes': ub}
-    achieved = kbytes / (kms * 1e-3) / 1e9
-    # the committed counters were collected on the default workload: only that run may quote them
-    default_workload = (m, n, r, S, args.nnz, args.loss, args.item_dist, args.dtype) == \
-        (1_000_000, 100_000, 128, 1024, 100_000_000, 'wmrb', 'zipf', 'f32')
-    traffic, traffic_src = pmc_traffic(kname) if default_workload else (None, None)
-    roofline = dict(bound='hbm', kernel=kname, achieved=achieved, peak=HBM_PEAK / 1e9, unit='GB/s',
-                    frac=achieved / (HBM_PEAK / 1e9), traffic=traffic, traffic_source=traffic_src,
-                    traffic_rate_frac=(traffic / (kms * 1e-3) / HBM_PEAK) if traffic else None, kernel_ms=kms,
-                    alg_bytes_per_launch=kbytes,
-                    note='achieved counts ALGORITHMIC bytes (SURVEY 8d); gathers served by L2 / Infinity Cache let it exceed the HBM peak; '
-                         'traffic_rate_frac = measured fabric bytes (PMC) / kernel time / peak',
-                    epoch_alg_bytes=ub + ib, epoch_frac=(ub + ib) / (ms_per_step * 1e-3) / HBM_PEAK, **other)
+    # ---- roofline: one entry per kernel, the dominant one (by time) on top ----
+    default_workload = (args.users, args.items, args.r, args.samples, args.nnz, args.loss, args.item_dist, args.dtype, world) == \
+        (1_000_000, 100_000, 128, 1024, 100_000_000, 'wmrb', 'zipf', 'f32', 1)
+    pmc, pmc_src = pmc_traffic() if default_workload else (None, 'only quoted on the default workload')
+    models = wl.models()
+    kernels = roofline_report(models, prof, pmc)
+    top = kernels[0]
+    roofline = dict(bound=top['bound'], kernel=top['kernel'], achieved=top['achieved'], peak=top['peak'], unit='GB/s', frac=top['frac'],
+                    traffic=top.get('traffic'), hbm_traffic_frac=top.get('hbm_traffic_frac'), traffic_source=pmc_src,
+                    kernel_ms=top['ms'], kernels=kernels, csrc_sha=csrc_sha(),
+                    epoch_hbm_bytes=sum(k['hbm'] for k in models.values()),
+                    epoch_hbm_frac=sum(k['hbm'] for k in models.values()) / (ms_per_step * 1e-3) / HBM_PEAK,
+                    epoch_gather_bytes=sum(k['gather'] for k in models.values()),
+                    epoch_gather_rate_GBps=sum(k['gather'] for k in models.values()) / (ms_per_step * 1e-3) / 1e9,
+                    l2_gather_rate_measured_by_guide_GBps=[x / 1e9 for x in L2_GATHER_MEASURED],
+                    note='bound=l2: the kernel is blocked so that the rows it gathers come from the XCD L2s; achieved = gathered row bytes / '
+                         'kernel time against the 34.5 TB/s aggregate L2 rate (the guide measures 16.8-18.8 TB/s for L2-resident row '
+                         'gathers). hbm_* = bytes that must cross HBM at least once against 8 TB/s; traffic = PMC fabric bytes of this '
+                         'code version (csrc_sha) or null.')
+    wplan = wl.wplan
+    if wplan is not None:
+        roofline.update(wmrb_user_pass_ms=prof.mean_ms('wmrb_user_pass'), wmrb_item_pass_ms=prof.mean_ms('wmrb_item_pass'),
+                        wmrb_user_pass_form=(f'sliced: scores + hinge + gradU + finish kernels over {wplan.n_slices} item slice(s)'
+                                             if wplan.sliced else 'fused single kernel'),
+                        wmrb_item_lists_user_blocks=wplan.user_chunks)
 
     out = dict(metric='train_interactions_per_sec', value=nnz_total / (elapsed / args.steps), unit='interactions/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
-               scaling='weak', vs_baseline=None, dtype='f32' if args.dtype == 'f32' else 'bf16 storage / f32 arithmetic',
+               scaling=args.scaling if world > 1 else 'weak', vs_baseline=None,
+               dtype='f32' if args.dtype == 'f32' else 'bf16 storage / f32 arithmetic',
                data='synthetic' + (' (REHEARSAL: all ranks on one card, host-staged gloo collectives - timings invalid)' if rehearse else ''),
-               config=dict(workload=f'C4: {m} users x {n} items per GPU, r={r}, {args.loss.upper()}'
-                                    + (f' S={S}' if args.loss == 'wmrb' else '') + f', item ids {args.item_dist}, '
-                                    f'lognormal user degrees', interactions_per_gpu=nnz, positives_per_gpu=plan.n_pos,
-                           parallelism=f'user-partition dp{world}', lr=args.lr),
+               config=dict(workload=wl.describe('C4' if (args.users, args.items, args.r) == (1_000_000, 100_000, 128) else 'custom')
+                           + (f' (strong scaling: users {wl.user_block[0]}..{wl.user_block[1]} of {args.users} on rank 0)' if strong and world > 1 else ''),
+                           interactions_per_gpu=wl.nnz, interactions_total=nnz_total, positives_per_gpu=wl.plan.n_pos,
+                           parallelism=f'user-partition dp{world}', lr=args.lr, warmup_ms_per_step=warm_elapsed / max(args.warmup, 1) * 1e3),
                roofline=roofline)
+    if comm is not None:
+        out['collectives'] = comm
 
     if rank == 0 and not args.no_extras and world == 1:
-        losses = loss_buf[:args.steps + args.warmup].cpu().numpy() / (plan.n_pos if args.loss == 'wmrb' else nnz)
+        denom = wl.plan.n_pos if args.loss == 'wmrb' else wl.nnz
+        losses = loss_buf[:args.steps + args.warmup].cpu().numpy() / denom
         out['loss_first_last'] = [float(losses[0]), float(losses[-1])]
-        out['cpu_baseline'] = cpu_baseline(args.loss, idx, val, R, U0, V0[:n], n, S, args.lr)
+        out['cpu_baseline'] = cpu_baseline(args.loss, wl.idx, wl.val, wl.R, wl.U0, wl.V0[:wl.n], wl.n, wl.S, args.lr)
         # predict rows/s: stable top-10 over the full catalog, fused GEMM + top-k (no [m, n] matrix)
-        Ue, Ve = st.U[:, :r], st.V[:n, :r]
-        rows = min(m, 262144)
+        Ue, Ve = wl.st.U[:, :wl.r], wl.st.V[:wl.n, :wl.r]
+        rows = min(wl.m, 262144)
         _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -405,13 +594,21 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         out['predict_rows_per_sec'] = rows / dt
-        out['predict_tflops'] = 2.0 * rows * n * r / dt / 1e12
-        out['predict_note'] = (f'stable top-10 of U.V^T over all {n} items for {rows} users, fused MFMA GEMM + top-k '
+        out['predict_tflops'] = 2.0 * rows * wl.n * wl.r / dt / 1e12
+        out['predict_note'] = (f'stable top-10 of U.V^T over all {wl.n} items for {rows} users, fused MFMA GEMM + top-k '
                                + ('(tmf_predict_topk_bf16: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)' if args.dtype == 'bf16'
                                   else '(tmf_predict_topk_f32: exact-fp32 MFMA, peak 157.3 TF)'))
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want),
                                    case='C1 golden fixture: ranking of the oracle-trained tables (450 epochs)')
+        # the same epochs through the public API (fit re-initialises, so it runs warmup + steps epochs from the same start)
+        engine_ms = (elapsed + warm_elapsed) / (args.steps + args.warmup) * 1e3
+        del Ue, Ve
+        wl.st = None
+        torch.cuda.empty_cache()
+        out['api_fit'] = api_fit(dev, wl, args, args.steps + args.warmup)
+        out['api_fit'].update(engine_ms_per_epoch_same_epochs=engine_ms,
+                              api_over_engine=out['api_fit']['ms_per_epoch'] / engine_ms)
     if rank == 0 and world == 1 and (args.small_configs or not args.no_extras):
         # the reference's own (dense, full-batch) formulation on the host cores next to the engine, BASELINE configs 1-3
         out['reference_formulation_cpu'] = small_configs(dev, quick=not args.small_configs)
@@ -420,6 +617,14 @@ def main():
             out['recall_at_10']['end_to_end_C2'] = dict(engine=c2['recall_at_10'], oracle=c2['recall_at_10_cpu_restatement'],
                                                         abs_diff=c2['recall_at_10_abs_diff'],
                                                         case='C2 (943 x 1682, r=32, MSE): 100 epochs trained by each side from the same start')
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_legs and default_workload:
+        # workloads whose factor rows really come from HBM (the C4 tables sit in L2 / Infinity Cache): DESIGN.md §4
+        del wl
+        torch.cuda.empty_cache()
+        out['hbm_legs'] = dict(
+            c4_mse=hbm_leg(args, dev, 'C4 shape, MSE', 1_000_000, 100_000, 100_000_000, 128, 1024, 'mse', 'f32', 20, 5),
+            c5_shard_bf16=hbm_leg(args, dev, 'config-5 shard (1/8 of 10M x 1M)', 1_250_000, 1_000_000, 125_000_000, 256, 1024, 'wmrb',
+                                  'bf16', 5, 2))
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
     if dp_mode:

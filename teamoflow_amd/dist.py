@@ -69,8 +69,12 @@ class HipBackend:
     def V(self):
         return self.st.V
 
+    def V_next(self):
+        """Where the all-gather assembles the updated table: the other half of the double buffer (no copy afterwards)."""
+        return self.st.V_nxt
+
     def finish(self):
-        self.st.U, self.st.U_nxt = self.st.U_nxt, self.st.U
+        self.st.swap()
 
 
 def _staged(group, t):
@@ -122,23 +126,52 @@ class DataParallelEpoch:
         self.rows_per_rank = V.shape[0] // self.world
         self.g_shard = torch.empty(self.rows_per_rank, V.shape[1], dtype=torch.float32, device=V.device)
         self.stats = torch.zeros(2, dtype=torch.float64, device=V.device)
-        self.V_gather = torch.empty_like(V)  # all-gather target (kept separate from its input shard: no aliasing)
+        # all-gather target: the backend's other V buffer when it has one (it becomes the table of the next epoch, no
+        # copy), else a buffer of our own that is copied back; never the buffer the send rows live in (no aliasing)
+        self.V_gather = None if hasattr(backend, 'V_next') else torch.empty_like(V)
         self.local_count = float(local_count)
+        self.bytes = dict(reduce_scatter=V.numel() * 4, all_gather=V.numel() * V.element_size())
+        self._spans = {'reduce_scatter': [], 'all_gather': []}
+
+    def _timed(self, name, fn, t):
+        if not t.is_cuda:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self._spans[name].append((a, b))
 
     def step(self):
         """Returns the global mean loss as a 0-d fp64 tensor (no host sync)."""
         gV, loss_sum = self.b.local_passes()
-        reduce_scatter_sum(self.g_shard, gV, self.group)
+        self._timed('reduce_scatter', lambda: reduce_scatter_sum(self.g_shard, gV, self.group), gV)
         V = self.b.V()
         mine = V[self.rank * self.rows_per_rank:(self.rank + 1) * self.rows_per_rank]
         self.b.adam_rows(mine, self.g_shard)
-        all_gather_rows(self.V_gather, mine, self.group)
-        V.copy_(self.V_gather)
+        if self.V_gather is None:
+            out = self.b.V_next()
+            self._timed('all_gather', lambda: all_gather_rows(out, mine, self.group), mine)
+        else:
+            all_gather_rows(self.V_gather, mine, self.group)
+            V.copy_(self.V_gather)
         self.stats[0] = loss_sum.reshape(())
         self.stats[1] = self.local_count
         all_reduce_sum(self.stats, self.group)
         self.b.finish()
         return self.stats[0] / self.stats[1]
+
+    def comm_report(self):
+        """Mean milliseconds of the two collectives on this rank (events on the launch stream, so queueing behind the
+        local passes is not included), their payloads, and the process group they ran on."""
+        def mean(spans):
+            v = [a.elapsed_time(b) for a, b in spans[1:]] or [a.elapsed_time(b) for a, b in spans]   # the first call builds the communicator
+            return sum(v) / len(v) if v else None
+        return dict(backend=dist.get_backend(self.group), ranks=self.world,
+                    reduce_scatter_ms=mean(self._spans['reduce_scatter']), reduce_scatter_bytes=self.bytes['reduce_scatter'],
+                    all_gather_ms=mean(self._spans['all_gather']), all_gather_bytes=self.bytes['all_gather'],
+                    note='per rank and epoch: reduce-scatter(sum) of the fp32 item gradient, all-gather of the updated item rows; '
+                         'not overlapped with compute (a few ms against ~100 ms of local passes at C4)')
 
 
 def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0, group=None):
@@ -146,31 +179,41 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
 
     Every rank passes the SAME global inputs (interactions, model.random_ind, initial weights); it keeps the
     users of its block (``partition_users``: balanced by interactions + negatives), trains them against the
-    replicated V and exchanges the item gradient once per epoch (``DataParallelEpoch``).  On return the model
-    holds ``item_embedding`` (replicated), ``user_embedding`` = this rank's block, ``user_block`` = (begin, end);
-    ``gather_user_embedding(model)`` assembles the full table."""
+    replicated V and exchanges the item gradient once per epoch (``DataParallelEpoch``).  A rank that only holds its
+    own users sets ``model.local_users = (begin, end)`` first: ``interactions`` (user ids relative to ``begin``),
+    ``model.random_ind`` and the user initialiser's rows are then this block's and nothing global is touched.
+    On return the model holds ``item_embedding`` (replicated), ``user_embedding`` = this rank's block,
+    ``user_block`` = (begin, end); ``gather_user_embedding(model)`` assembles the full table."""
     from .mf.loss_graphs import WMRBLoss
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = interactions.device
     wmrb = isinstance(model.loss_graph, WMRBLoss)
-    u = interactions.indices[:, 0]
-    rowptr = _engine._excl_cumsum(torch.bincount(u, minlength=n_users))
-    S = int(model.random_ind.shape[1]) if wmrb else 0
-    bounds = partition_users(rowptr, world, per_user_cost=S)
-    b, e = bounds[rank], bounds[rank + 1]
-    keep = (u >= b) & (u < e)
-    idx = interactions.indices[keep].clone()
-    idx[:, 0] -= b
-    val = interactions.values[keep]
+    local = getattr(model, 'local_users', None)
+    if local is not None:
+        b, e = int(local[0]), int(local[1])
+        idx, val = interactions.indices, interactions.values
+        if tuple(torch.as_tensor(U0).shape)[0] != e - b:
+            raise ValueError(f'local_users = {local}: the user initialiser must return the {e - b} rows of this block')
+    else:
+        u = interactions.indices[:, 0]
+        rowptr = _engine._excl_cumsum(torch.bincount(u, minlength=n_users))
+        S = int(model.random_ind.shape[1]) if wmrb else 0
+        bounds = partition_users(rowptr, world, per_user_cost=S)
+        b, e = bounds[rank], bounds[rank + 1]
+        keep = (u >= b) & (u < e)
+        idx = interactions.indices[keep].clone()
+        idx[:, 0] -= b
+        val = interactions.values[keep]
     n_pad = padded_rows(n_items, world)
     plan = _engine.InteractionPlan(idx, val, e - b, n_pad, user_chunks=1 if wmrb else _engine.mse_user_chunks(), csc=not wmrb)
     ld = _lib.padded_ld(model.n_components, model.factor_dtype)
     wplan, c = None, 0.0
     if wmrb:
         Rall = torch.as_tensor(model.random_ind)
-        if Rall.dim() != 2 or Rall.shape[0] != n_users:
-            raise ValueError(f'random_ind has shape {tuple(Rall.shape)}, expected [{n_users}, n_samples]')
-        R = Rall[b:e].to(device=dev, dtype=torch.int32).contiguous()
+        want_rows = e - b if local is not None else n_users
+        if Rall.dim() != 2 or Rall.shape[0] != want_rows:
+            raise ValueError(f'random_ind has shape {tuple(Rall.shape)}, expected [{want_rows}, n_samples]')
+        R = (Rall if local is not None else Rall[b:e]).to(device=dev, dtype=torch.int32).contiguous()
         if R.numel() and (int(R.min()) < 0 or int(R.max()) >= n_items):
             raise IndexError('random_ind holds item ids outside [0, n_items)')
         c = model.n_items / model.n_samples
@@ -178,7 +221,8 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
                                  item_slices=_engine.default_item_slices(n_pad, ld), n_components=model.n_components)
     V0p = torch.zeros(n_pad, model.n_components, dtype=torch.float32, device=dev)
     V0p[:n_items] = torch.as_tensor(V0).detach().to(device=dev, dtype=torch.float32)
-    st = _engine.TrainState(torch.as_tensor(U0).detach()[b:e], V0p, plan, model.n_components, wplan, dtype=model.factor_dtype)
+    U_blk = torch.as_tensor(U0).detach() if local is not None else torch.as_tensor(U0).detach()[b:e]
+    st = _engine.TrainState(U_blk, V0p, plan, model.n_components, wplan, dtype=model.factor_dtype)
     adam = _engine.adam_constants(lr)
     backend = HipBackend(st, 'wmrb' if wmrb else 'mse', c, adam)
     dp = DataParallelEpoch(backend, plan.n_pos if wmrb else plan.nnz, group=group)

@@ -87,6 +87,7 @@ class MatrixFactorization:
 
         self.loss_history_ = []   # extension: mean loss of every epoch of the last fit
         self.fit_seconds_ = 0.0   # extension: time spent in the epoch loop of the last fit
+        self.plan_seconds_ = 0.0  # extension: time spent building the index structures of the last fit
         self.verbose = True
         self.factor_dtype = torch.float32  # extension: torch.bfloat16 = bf16 factor storage, fp32 arithmetic
         self.data_parallel = False         # extension: split the users over torch.distributed ranks (teamoflow_amd/dist.py)
@@ -126,6 +127,7 @@ class MatrixFactorization:
     def _fit_sparse(self, epochs, n_users, n_items, interactions, lr, U0, V0):
         _lib.get()  # fail loudly here when the HIP engine cannot run
         dev = default_device()
+        t_plan = timeit.default_timer()
         if interactions.device != dev:
             interactions = interactions.to(dev)
         wmrb = isinstance(self.loss_graph, WMRBLoss)
@@ -171,6 +173,7 @@ class MatrixFactorization:
         use_graph = G >= 4 and work <= GRAPH_MAX_WORK and os.environ.get('TMF_NO_GRAPH') is None
         torch.cuda.synchronize(dev)
         t0 = timeit.default_timer()
+        self.plan_seconds_ = t0 - t_plan  # extension: index structures + table set-up of this fit (once, not per epoch)
         done = 0
         if use_graph:
             block = torch.zeros(G, dtype=torch.float64, device=dev)

@@ -110,3 +110,21 @@ def test_partition_users_balances_cost():
     assert b[0] == 0 and b[-1] == 8 and all(x <= y for x, y in zip(b, b[1:]))
     assert partition_users(np.array([0]), 4) == [0, 0, 0, 0, 0]
     assert padded_rows(100000, 8) == 100000 and padded_rows(10, 4) == 12
+
+
+def test_partition_with_more_ranks_than_users_and_empty_plans():
+    """Skewed costs or world > n_users give empty user blocks: the boundaries stay monotone and a rank with no users
+    still builds valid (empty) plans - its passes are no-ops and it only takes part in the collectives."""
+    from teamoflow_amd._engine import InteractionPlan, WmrbPlan
+    from teamoflow_amd.dist import partition_users
+    rowptr = np.concatenate([[0], np.cumsum([1000, 1, 1])])
+    for world in (2, 4, 8):
+        b = partition_users(rowptr, world, per_user_cost=3)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == 3 and all(x <= y for x, y in zip(b, b[1:]))
+    assert any(x == y for x, y in zip(b, b[1:]))          # at 8 ranks some block is empty
+    n, S = 7, 3
+    plan = InteractionPlan(torch.zeros(0, 2, dtype=torch.int64), torch.zeros(0), 0, n)
+    assert plan.nnz == 0 and plan.rowptr_u.tolist() == [0] and plan.seg_u.nseg == 0 and plan.n_pos == 0
+    for slices in (1, 3):
+        w = WmrbPlan(plan, torch.zeros(0, S, dtype=torch.int32), user_chunks=2, item_slices=slices)
+        assert w.ent_row.numel() == 0 and w.rowptr_e.tolist() == [0] * (2 * n + 1) and tuple(w.D.shape) == (0, S)
