@@ -211,10 +211,15 @@ int tmf_predict_gemm_f32(const float* A, const float* B, float* C, int64_t m, in
                          int64_t lda, int64_t ldb, int64_t ldc, void* stream);
 
 /* K8: row-wise top-k of X [rows, cols] ordered (value desc, index asc) - tf.math.top_k's contract
- * (matrix_factorization.py:245,429-438).  clamp_negatives != 0 first maps x <= 0 to 0.0
- * (matrix_factorization.py:237).  out_idx [rows, k] int32, out_val optional [rows, k]. */
+ * (matrix_factorization.py:245,429-438), any k in [1, cols] including the full ranking retrieve_user_recs(k=None) and
+ * dcg / ndcg ask for (:336,:367,:424-438).  clamp_negatives != 0 first maps x <= 0 to 0.0 (matrix_factorization.py:237).
+ * out_idx [rows, k] int32, out_val optional [rows, k].  k <= 64, or rows of at most 16384 columns, need no workspace;
+ * larger k over wider rows is a stable segmented radix sort through `workspace` (tmf_topk_workspace_bytes; rows * cols
+ * < 2^32 per call). */
+size_t tmf_topk_workspace_bytes(int64_t rows, int64_t cols, int k);
 int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, int k,
-                        int clamp_negatives, int32_t* out_idx, float* out_val, void* stream);
+                        int clamp_negatives, int32_t* out_idx, float* out_val, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* bf16-storage / fp32-arithmetic variants (BASELINE config 5: "bf16 factors / fp32 accum"; an extension - the
  * reference is fp32 throughout).  Tables are bf16 row-major [rows, tmf_padded_ld_bf16(r)]; every product,
@@ -240,7 +245,7 @@ int tmf_adam_fresh_rows_bf16(void* W, const float* G, int64_t n_rows, int n_comp
 
 /* K7+K8 fused: out_idx[u, :k] = top-k (value desc, index asc) of A[u, :r] . B[:, :r]^T over all n items,
  * without materialising the [m, n] scores (recall_at_k / retrieve_user_recs, matrix_factorization.py:236-248,
- * :424-438, at catalog sizes where the dense matrix does not fit).  Supports k <= 32 and r <= 128; returns
+ * :424-438, at catalog sizes where the dense matrix does not fit).  Supports k <= 64 and r <= 128; returns
  * TMF_E_UNSUPPORTED otherwise (callers then score block-wise with tmf_predict_gemm_f32 + tmf_topk_stable_f32). */
 int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
                          int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,

@@ -82,7 +82,8 @@ _BASE_SIGNATURES = {
     'tmf_sum_f32': (_I, [_P, _L, _P, _P]),
     'tmf_gather_rows_cols_f32': (_I, [_P, _P, _P, _L, _L, _L, _P]),
     'tmf_predict_gemm_f32': (_I, [_P, _P, _P, _L, _L, _I, _L, _L, _L, _P]),
-    'tmf_topk_stable_f32': (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
+    'tmf_topk_workspace_bytes': (_SZ, [_L, _L, _I]),
+    'tmf_topk_stable_f32': (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _SZ, _P]),
     'tmf_predict_topk_f32': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P]),
     'tmf_predict_topk_bf16': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P]),
 }

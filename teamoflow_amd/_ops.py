@@ -42,7 +42,8 @@ def predict_gemm(user_embedding, item_embedding, out=None):
     return out
 
 
-FUSED_MAX_K, FUSED_MAX_R, FUSED_MAX_R_BF16 = 32, 128, 256
+FUSED_MAX_K, FUSED_MAX_K_BF16, FUSED_MAX_R, FUSED_MAX_R_BF16 = 64, 32, 128, 256
+SORT_MAX_ELEMS = 1 << 29   # elements ranked per call of the wide-row path (2 GB of keys + 2 GB of ids, twice)
 
 
 def _bf16_operand(t):
@@ -60,13 +61,13 @@ def _bf16_operand(t):
 
 def fused_topk_supported(user_embedding, item_embedding, k):
     bf16 = user_embedding.dtype == torch.bfloat16 and item_embedding.dtype == torch.bfloat16
-    return k <= FUSED_MAX_K and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
+    return k <= (FUSED_MAX_K_BF16 if bf16 else FUSED_MAX_K) and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
 
 
 def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False):
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
-    fp32 tables: exact-fp32 MFMA, k <= 32, width <= 128.  bf16 tables (both operands): bf16 MFMA with fp32
-    accumulation, width <= 256.  See topk_stable(predict_gemm(...)) for the general case."""
+    fp32 tables: exact-fp32 MFMA, k <= 64, width <= 128.  bf16 tables (both operands): bf16 MFMA with fp32
+    accumulation, k <= 32, width <= 256.  See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
     if torch.is_tensor(user_embedding) and torch.is_tensor(item_embedding) and \
             user_embedding.dtype == torch.bfloat16 and item_embedding.dtype == torch.bfloat16:
@@ -111,8 +112,17 @@ def topk_stable(x, k, clamp_negatives=False, return_values=False):
         raise ValueError(f'k={k} must be in [1, {cols}]')  # tf.math.top_k raises for k > last dim
     idx = torch.empty(rows, k, dtype=torch.int32, device=x.device)
     vals = torch.empty(rows, k, dtype=torch.float32, device=x.device) if return_values else None
-    _lib.check(lib.tmf_topk_stable_f32(_lib.ptr(x), rows, cols, x.stride(0), k, int(bool(clamp_negatives)),
-                                       _lib.ptr(idx), _lib.ptr(vals), _lib.stream_ptr()), lib)
+    # large k over wide rows goes through a segmented radix sort with a workspace: a bounded number of rows per call
+    step = rows if lib.tmf_topk_workspace_bytes(1, cols, k) == 0 else max(1, SORT_MAX_ELEMS // cols)
+    ws = None
+    for b in range(0, rows, step):
+        e = min(b + step, rows)
+        need = lib.tmf_topk_workspace_bytes(e - b, cols, k)
+        if need and (ws is None or ws.numel() < need):
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.tmf_topk_stable_f32(_lib.ptr(x[b:e]), e - b, cols, x.stride(0), k, int(bool(clamp_negatives)),
+                                           _lib.ptr(idx[b:e]), _lib.ptr(vals[b:e]) if return_values else None, _lib.ptr(ws),
+                                           ws.numel() if ws is not None else 0, _lib.stream_ptr()), lib)
     if squeeze:
         idx = idx[0]
         vals = vals[0] if return_values else None

@@ -1,6 +1,10 @@
 // K7 predict GEMM on the exact-fp32 MFMA, K8 tie-stable row top-k, and gather_matrix_indices.
 #include <math.h>
 
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
 #include "tmf_common.h"
 
 namespace tmf {
@@ -205,6 +209,54 @@ __global__ __launch_bounds__(1024) void k_sort_rows(const float* __restrict__ X,
     }
 }
 
+// Rows wider than the LDS sort holds (k > 64 and cols > 16384: full rankings and large k on real catalogs): keys and
+// column ids go through rocPRIM's segmented radix sort in DESCENDING key order.  Radix sort is stable, so equal values
+// keep their ascending column order - tf.math.top_k's rule; -0.0 is stored as +0.0 so that the two compare equal.
+__global__ __launch_bounds__(256) void k_rank_prepare(const float* __restrict__ X, int64_t rows, int64_t cols, int64_t ldx,
+                                                      int clamp, float* __restrict__ keys, int32_t* __restrict__ ids) {
+    const int64_t total = rows * cols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / cols, c = t - r * cols;
+        float v = X[r * ldx + c];
+        if (clamp) v = (v > 0.f) ? v : 0.f;
+        keys[t] = (v == 0.f) ? 0.f : v;
+        ids[t] = (int32_t)c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rank_emit(const float* __restrict__ keys, const int32_t* __restrict__ ids, int64_t rows,
+                                                   int64_t cols, int k, int32_t* __restrict__ out_idx,
+                                                   float* __restrict__ out_val) {
+    const int64_t total = rows * k;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / k, j = t - r * k;
+        out_idx[t] = ids[r * cols + j];
+        if (out_val) out_val[t] = keys[r * cols + j];
+    }
+}
+
+struct RankRowStart {
+    unsigned int stride;
+    __host__ __device__ unsigned int operator()(unsigned int row) const { return row * stride; }
+};
+
+static size_t rank_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t rank_sort_temp(int64_t rows, int64_t cols) {
+    size_t bytes = 0;
+    auto offs = rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), RankRowStart{(unsigned)cols});
+    (void)rocprim::segmented_radix_sort_pairs_desc(nullptr, bytes, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr,
+                                                   (int32_t*)nullptr, (unsigned)(rows * cols), (unsigned)rows, offs, offs + 1, 0, 32,
+                                                   (hipStream_t)0);
+    return bytes;
+}
+
+static bool rank_needs_global_sort(int64_t cols, int k) {
+    int64_t npow2 = 1;
+    while (npow2 < cols) npow2 <<= 1;
+    return k > 64 && npow2 * 8 > 160 * 1024;
+}
+
 __global__ __launch_bounds__(256) void k_gather_rows_cols(const float* __restrict__ X, const int64_t* __restrict__ idx,
                                                           float* __restrict__ out, int64_t rows, int64_t cols, int64_t k) {
     const int64_t total = rows * k;
@@ -232,8 +284,14 @@ extern "C" int tmf_predict_gemm_f32(const float* A, const float* B, float* C, in
     return check_launch("tmf_predict_gemm_f32");
 }
 
+extern "C" size_t tmf_topk_workspace_bytes(int64_t rows, int64_t cols, int k) {
+    if (rows <= 0 || cols <= 0 || !rank_needs_global_sort(cols, k) || rows * cols >= ((int64_t)1 << 32)) return 0;
+    return 4 * rank_align((size_t)(rows * cols) * 4) + rank_align(rank_sort_temp(rows, cols));
+}
+
 extern "C" int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, int k,
-                                   int clamp_negatives, int32_t* out_idx, float* out_val, void* stream) {
+                                   int clamp_negatives, int32_t* out_idx, float* out_val, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
     if (rows == 0) return TMF_OK;
     TMF_REQUIRE(X && out_idx && rows > 0 && cols > 0 && ldx >= cols, "topk: bad arguments");
     TMF_REQUIRE(k >= 1 && k <= cols, "topk: k=%d must be in [1, cols=%lld]", k, (long long)cols);
@@ -249,13 +307,34 @@ extern "C" int tmf_topk_stable_f32(const float* X, int64_t rows, int64_t cols, i
                                ldx, k, clamp_negatives, out_idx, out_val);
         return check_launch("tmf_topk_stable_f32");
     }
+    if (rank_needs_global_sort(cols, k)) {
+        TMF_REQUIRE(rows * cols < ((int64_t)1 << 32), "topk: rows * cols >= 2^32 in one call: pass fewer rows");
+        const size_t need = tmf_topk_workspace_bytes(rows, cols, k);
+        TMF_REQUIRE(workspace && workspace_bytes >= need, "topk: k=%d over %lld columns needs a workspace of tmf_topk_workspace_bytes() "
+                    "= %zu bytes", k, (long long)cols, need);
+        char* w = static_cast<char*>(workspace);
+        const size_t a4 = rank_align((size_t)(rows * cols) * 4);
+        float* keys_in = reinterpret_cast<float*>(w);
+        float* keys_out = reinterpret_cast<float*>(w + a4);
+        int32_t* ids_in = reinterpret_cast<int32_t*>(w + 2 * a4);
+        int32_t* ids_out = reinterpret_cast<int32_t*>(w + 3 * a4);
+        size_t temp_bytes = workspace_bytes - 4 * a4;
+        const int64_t want = (rows * cols + 255) / 256;
+        const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(k_rank_prepare, dim3(grid), dim3(256), 0, s, X, rows, cols, ldx, clamp_negatives, keys_in, ids_in);
+        auto offs = rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), RankRowStart{(unsigned)cols});
+        hipError_t e = rocprim::segmented_radix_sort_pairs_desc(w + 4 * a4, temp_bytes, keys_in, keys_out, ids_in, ids_out,
+                                                                (unsigned)(rows * cols), (unsigned)rows, offs, offs + 1, 0, 32, s);
+        if (e != hipSuccess) { set_error("segmented_radix_sort_pairs_desc: %s", hipGetErrorString(e)); return TMF_E_LAUNCH; }
+        const int64_t want2 = (rows * k + 255) / 256;
+        hipLaunchKernelGGL(k_rank_emit, dim3((unsigned)(want2 < 8192 ? want2 : 8192)), dim3(256), 0, s, (const float*)keys_out,
+                           (const int32_t*)ids_out, rows, cols, k, out_idx, out_val);
+        return check_launch("tmf_topk_stable_f32");
+    }
     int npow2 = 1;
     while (npow2 < cols) npow2 <<= 1;
     const size_t lds = (size_t)npow2 * 8;
-    if (lds > 160 * 1024) {
-        set_error("topk: full ranking of %lld columns needs %zu bytes of LDS (max 163840); use k <= 64", (long long)cols, lds);
-        return TMF_E_UNSUPPORTED;
-    }
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_sort_rows), lds, grant)) return rc;
     const int threads = npow2 / 2 < 1024 ? (npow2 / 2 < 64 ? 64 : npow2 / 2) : 1024;
@@ -291,7 +370,7 @@ extern "C" int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, floa
 // =============================================================================================
 namespace tmf {
 
-constexpr int FBM = 128, FBN = 128, FBK = 32, FLD = FBN + 1, FCAP = 16, FMAXK = 32;
+constexpr int FBM = 128, FBN = 128, FBK = 32, FLD = FBN + 1, FCAP = 16, FMAXK = 64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 2: K % 4 == 0 and V < 4 GB (buffer loads, constant per-thread offsets), 1: K % 4 == 0 (branch-free), 0: any K

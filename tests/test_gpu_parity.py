@@ -332,11 +332,11 @@ def test_topk_tie_rule_and_clamp(tm):
     z = torch.zeros(3, 1000)
     assert tm.ops.topk_stable(z, 10).cpu().tolist() == [list(range(10))] * 3
     rng = np.random.default_rng(5)
-    for cols in (1, 7, 64, 257, 1000, 4099):
-        y = torch.tensor(rng.integers(-3, 4, (17, cols)).astype(np.float32))  # many ties
-        for k in sorted({1, min(10, cols), min(64, cols), min(100, cols), cols}):
-            if k > 64 and cols > 16384:
-                continue
+    for cols in (1, 7, 64, 257, 1000, 4099, 16385, 100_003):   # the last two: wider than the in-LDS sort holds
+        y = torch.tensor(rng.integers(-3, 4, (17 if cols < 50_000 else 5, cols)).astype(np.float32))  # many ties
+        if cols > 1000:
+            y[1, ::3] = -0.0                                         # -0.0 ties with +0.0, lower index first
+        for k in sorted({1, min(10, cols), min(64, cols), min(100, cols), min(1000, cols), cols}):
             want = torch.sort(y, dim=1, descending=True, stable=True)[1][:, :k]
             got = tm.ops.topk_stable(y, k).cpu()
             assert torch.equal(got.to(torch.int64), want), (cols, k)
@@ -344,6 +344,46 @@ def test_topk_tie_rule_and_clamp(tm):
             assert torch.equal(tm.ops.topk_stable(y, k, clamp_negatives=True).cpu().to(torch.int64), wc), (cols, k)
     with pytest.raises(ValueError):
         tm.ops.topk_stable(x, 6)
+    # rows split over several calls of the wide path (workspace bounded), values returned too
+    big = torch.tensor(rng.standard_normal((6, 40_000)).astype(np.float32)).cuda()
+    old = tm.ops.SORT_MAX_ELEMS
+    tm.ops.SORT_MAX_ELEMS = 100_000
+    try:
+        vals, idx = tm.ops.topk_stable(big, 500, return_values=True)
+    finally:
+        tm.ops.SORT_MAX_ELEMS = old
+    sv, si = torch.sort(big, dim=1, descending=True, stable=True)
+    assert torch.equal(idx.to(torch.int64), si[:, :500]) and torch.equal(vals, sv[:, :500])
+
+
+def test_full_ranking_and_large_k_on_a_real_catalog(tm):
+    """retrieve_user_recs(user, k=None), k = 100 for every user, and the dcg / ndcg family at catalog widths the in-LDS
+    sort cannot hold (matrix_factorization.py:424-438, :332-413): bit-equal to the oracle's stable ranking."""
+    from oracle import dense_ref as D
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(31)
+    m, n, r = 40, 100_000, 16
+    U = rng.integers(-2, 3, (m, r)).astype(np.float32)      # small integers: many exact score ties
+    V = rng.integers(-2, 3, (n, r)).astype(np.float32)
+    model = tm.MF(r, n_users=m, n_items=n)
+    model.user_embedding, model.item_embedding = torch.tensor(U).cuda(), torch.tensor(V).cuda()
+    sc = U @ V.T
+    full = model.retrieve_user_recs(user=3)
+    assert full.dtype == np.int32 and np.array_equal(full, S.topk_stable(sc[3:4], n)[0])
+    assert np.array_equal(model.retrieve_user_recs(k=100), S.topk_stable(sc, 100))       # k > 64: block-wise scores + sort
+    assert np.array_equal(model.retrieve_user_recs(k=64), S.topk_stable(sc, 64))         # fused kernel, largest k
+    assert np.array_equal(model.retrieve_user_recs(), S.topk_stable(sc, n))              # every user's full ranking
+    n2 = 20_000
+    A = ((rng.random((m, n2)) < 0.01) * rng.integers(1, 6, (m, n2))).astype(np.float32)
+    model.item_embedding = model.item_embedding[:n2]
+    Un = U / 8
+    model.user_embedding = torch.tensor(Un).cuda()
+    for k in (10, 100):
+        got = model.ndcg_at_k(torch.tensor(A), k, preserve_rows=True).cpu().numpy()
+        assert np.allclose(got, D.ndcg_at_k_dense(Un, V[:n2], A, k, preserve_rows=True), rtol=1e-5, atol=1e-7)
+        assert rel_err(model.dcg_at_k(torch.tensor(A), k).cpu().numpy(), D.dcg_at_k_dense(Un, V[:n2], A, k)) < 1e-5
+        rec = model.recall_at_k(torch.tensor(A), k).cpu().numpy()
+        assert np.array_equal(rec, D.recall_at_k_dense(Un, V[:n2], A, k))
 
 
 def test_fused_predict_topk_matches_materialised_and_oracle(tm):
@@ -357,7 +397,7 @@ def test_fused_predict_topk_matches_materialised_and_oracle(tm):
             V[n - 3:] = V[7]
         Ut, Vt = torch.tensor(U), torch.tensor(V)
         scores = tm.ops.predict_gemm(Ut, Vt)
-        for k in sorted({1, min(10, n), min(32, n)}):
+        for k in sorted({1, min(10, n), min(32, n), min(33, n), min(64, n)}):
             for clamp in (False, True):
                 want = tm.ops.topk_stable(scores, k, clamp_negatives=clamp).cpu()
                 got_v, got = tm.ops.predict_topk(Ut, Vt, k, clamp_negatives=clamp, return_values=True)
@@ -707,8 +747,13 @@ def test_c_abi_error_codes_and_messages(tm):
     s = tm.lib.stream_ptr()
     x = torch.zeros(8, 8, device='cuda')
     out = torch.zeros(8, 8, device='cuda', dtype=torch.int32)
-    rc = lib.tmf_topk_stable_f32(tm.lib.ptr(x), 8, 8, 8, 9, 0, tm.lib.ptr(out), None, s)        # k > cols
+    rc = lib.tmf_topk_stable_f32(tm.lib.ptr(x), 8, 8, 8, 9, 0, tm.lib.ptr(out), None, None, 0, s)        # k > cols
     assert rc == -1 and b'k=9' in lib.tmf_last_error()
+    wide = torch.zeros(2, 20000, device='cuda')
+    wout = torch.zeros(2, 100, device='cuda', dtype=torch.int32)
+    assert lib.tmf_topk_workspace_bytes(2, 20000, 64) == 0 and lib.tmf_topk_workspace_bytes(2, 20000, 100) > 0
+    rc = lib.tmf_topk_stable_f32(tm.lib.ptr(wide), 2, 20000, 20000, 100, 0, tm.lib.ptr(wout), None, None, 0, s)   # no workspace
+    assert rc == -1 and b'workspace' in lib.tmf_last_error()
     rc = lib.tmf_predict_topk_f32(tm.lib.ptr(x), tm.lib.ptr(x), 8, 8, 8, 8, 8, 33, 0, tm.lib.ptr(out), None, s)  # k > 32
     assert rc == -1 or rc == -3
     big = torch.zeros(4, 132, device='cuda')
@@ -772,7 +817,7 @@ def test_randomized_fused_topk(tm, seed):
     rng = np.random.default_rng(7000 + seed)
     m, n = int(rng.integers(1, 400)), int(rng.integers(1, 3000))
     r = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128]))
-    k = int(min(n, rng.choice([1, 2, 5, 10, 17, 32])))
+    k = int(min(n, rng.choice([1, 2, 5, 10, 17, 32, 50, 64])))
     span = int(rng.choice([1, 2, 4]))
     U = rng.integers(-span, span + 1, (m, r)).astype(np.float32)
     V = rng.integers(-span, span + 1, (n, r)).astype(np.float32)
@@ -781,6 +826,7 @@ def test_randomized_fused_topk(tm, seed):
     ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
     got = tm.ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp).cpu().numpy()
     assert np.array_equal(got, ref), (m, n, r, k, clamp, 'f32')
-    gb = tm.ops.predict_topk(torch.tensor(U).to(torch.bfloat16).cuda(), torch.tensor(V).to(torch.bfloat16).cuda(), k,
-                             clamp_negatives=clamp).cpu().numpy()
-    assert np.array_equal(gb, ref), (m, n, r, k, clamp, 'bf16')
+    if k <= tm.ops.FUSED_MAX_K_BF16:
+        gb = tm.ops.predict_topk(torch.tensor(U).to(torch.bfloat16).cuda(), torch.tensor(V).to(torch.bfloat16).cuda(), k,
+                                 clamp_negatives=clamp).cpu().numpy()
+        assert np.array_equal(gb, ref), (m, n, r, k, clamp, 'bf16')
