@@ -196,6 +196,14 @@ int tmf_wmrb_finish_bf16(const float* part, int32_t n_slices, int32_t n_users, c
 int tmf_adam_fresh_rows_f32(float* W, const float* G, int64_t n_rows, int n_components,
                             tmf_adam adam, void* stream);
 
+/* OPT-IN EXTENSION, not the reference's optimiser (which is rebuilt every epoch, matrix_factorization.py:176): Keras
+ * Adam with persistent moments.  tmf_adam_step gives the scalars of iteration `step` (1-based; step 1 == tmf_adam_fresh),
+ * tmf_adam_state_rows_f32 applies one step in place to a whole [n_rows, ld] table from its raw gradient G (the
+ * TMF_EPI_GRAD output of the passes) and the moment tables M, V (zero before the first step). */
+tmf_adam tmf_adam_step(float lr, int step);
+int tmf_adam_state_rows_f32(float* W, const float* G, float* M, float* V, int64_t n_rows, int n_components,
+                            tmf_adam adam, void* stream);
+
 /* Deterministic sum of `n` floats into out[0] (fp64 accumulate, fixed order) - the reduce_mean
  * numerator of matrix_factorization.py:179. */
 int tmf_sum_f32(const float* x, int64_t n, double* out, void* stream);

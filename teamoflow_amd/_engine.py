@@ -387,21 +387,23 @@ def _row_pass_finish(lib, seg, slab, X_old, X_out, r, epi, adam, stream, sfx='_f
                                             _lib.ptr(slab), _lib.ptr(X_old), _lib.ptr(X_out), r, epi, adam, stream), lib)
 
 
-def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):
+def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None, user_epi=_lib.EPI_ADAM, user_out=None):
     """One MSE epoch: user pass (+loss), item pass; both read the pre-update tables.
     loss_out: 1-element fp64 device tensor receiving sum_k (a_k - p_k)^2.
-    item_epi=EPI_GRAD writes the raw item gradient into item_out (multi-GPU)."""
+    item_epi / user_epi = EPI_GRAD write the raw fp32 gradient into item_out / user_out instead of the updated table
+    (multi-GPU; optimisers other than the reference's)."""
     lib, p, r = _lib.get(), st.plan, st.r
     s = _lib.stream_ptr()
+    U_out = st.U_nxt if user_out is None else user_out
     if prof:
         prof.start('mse_user_pass')
     mse_pass = getattr(lib, 'tmf_mse_pass' + st.sfx)
     _lib.check(mse_pass(p.seg_u.cstruct(), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(st.U),
-                                    _lib.ptr(st.V), _lib.ptr(st.U_nxt), _lib.ptr(st.slab), _lib.ptr(st.loss_part),
-                                    r, _lib.EPI_ADAM, adam, s), lib)
+                                    _lib.ptr(st.V), _lib.ptr(U_out), _lib.ptr(st.slab), _lib.ptr(st.loss_part),
+                                    r, user_epi, adam, s), lib)
     if prof:
         prof.stop('mse_user_pass')
-    _row_pass_finish(lib, p.seg_u, st.slab, st.U, st.U_nxt, r, _lib.EPI_ADAM, adam, s, st.sfx)
+    _row_pass_finish(lib, p.seg_u, st.slab, st.U, U_out, r, user_epi, adam, s, st.sfx)
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.seg_u.nseg, _lib.ptr(loss_out), s), lib)
     V_out = st.V_nxt if item_out is None else item_out
     if prof:
@@ -413,7 +415,7 @@ def epoch_mse(st, adam, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=No
     _row_pass_finish(lib, p.seg_i, st.slab, st.V, V_out, r, item_epi, adam, s, st.sfx)
 
 
-def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None):
+def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None, user_epi=_lib.EPI_ADAM, U_out=None):
     """Sliced user pass: scores -> hinge -> gradU (+ weights into entry order) -> finish (csrc/tmf_wmrb.hip, tmf_hinge.hip)."""
     p, w, r = st.plan, st.wplan, st.r
     i32 = ctypes.c_int32
@@ -434,22 +436,24 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None):
     timed('wmrb_gradu', lambda: getattr(lib, 'tmf_wmrb_gradu3' + st.sfx)(
         lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(st.V), _lib.ptr(st.part), int(st.part_layers == 1 and ns > 1), r, s))
     timed('wmrb_finish', lambda: getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.part), i32(st.part_layers), i32(m),
-                                                                          _lib.ptr(st.U), _lib.ptr(st.U_nxt), r, _lib.EPI_ADAM, adam, s))
+                                                                          _lib.ptr(st.U), _lib.ptr(st.U_nxt if U_out is None else U_out),
+                                                                          r, user_epi, adam, s))
 
 
-def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None):
-    """One WMRB epoch.  loss_out receives sum over positives of log(1 + M_k)."""
+def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, prof=None, user_epi=_lib.EPI_ADAM, user_out=None):
+    """One WMRB epoch.  loss_out receives sum over positives of log(1 + M_k).  item_epi / user_epi as in epoch_mse."""
     lib, p, w, r = _lib.get(), st.plan, st.wplan, st.r
     s = _lib.stream_ptr()
     if prof:
         prof.start('wmrb_user_pass')
     if w.sliced:
-        _wmrb_user_pass_sliced(lib, st, adam, c, prof)
+        _wmrb_user_pass_sliced(lib, st, adam, c, prof, user_epi, user_out)
     else:
         _lib.check(getattr(lib, 'tmf_wmrb_user_pass' + st.sfx)(_lib.ptr(p.rowptr_u), _lib.ptr(p.col_u), _lib.ptr(p.val_u), _lib.ptr(w.R),
-                                              p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.U_nxt),
+                                              p.n_users, w.S, c, _lib.ptr(st.U), _lib.ptr(st.V),
+                                              _lib.ptr(st.U_nxt if user_out is None else user_out),
                                               _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), None,
-                                              r, _lib.EPI_ADAM, adam, s), lib)
+                                              r, user_epi, adam, s), lib)
     if prof:
         prof.stop('wmrb_user_pass')
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)

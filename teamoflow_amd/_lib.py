@@ -74,6 +74,8 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_gradu3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _I, _P]),
     'tmf_wmrb_finish_f32': (_I, [_P, _I32, _I32, _P, _P, _I, _I, Adam, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
+    'tmf_adam_step': (Adam, [_F, _I]),
+    'tmf_adam_state_rows_f32': (_I, [_P, _P, _P, _P, _L, _I, Adam, _P]),
     'tmf_mse_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_bf16': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),

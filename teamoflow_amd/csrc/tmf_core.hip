@@ -42,3 +42,15 @@ extern "C" tmf_adam tmf_adam_fresh(float lr) {
     a.eps = 1e-7f;
     return a;
 }
+
+extern "C" tmf_adam tmf_adam_step(float lr, int step) {
+    // Keras Adam at iteration `step` (1-based) in fp32: alpha_t = lr * sqrt(1 - b2^t) / (1 - b1^t); step 1 == tmf_adam_fresh
+    const float one = 1.0f, b1 = 0.9f, b2 = 0.999f;
+    tmf_adam a;
+    a.one_minus_b1 = one - b1;
+    a.one_minus_b2 = one - b2;
+    const float b1p = step <= 1 ? b1 : powf(b1, (float)step), b2p = step <= 1 ? b2 : powf(b2, (float)step);
+    a.alpha = lr * sqrtf(one - b2p) / (one - b1p);
+    a.eps = 1e-7f;
+    return a;
+}

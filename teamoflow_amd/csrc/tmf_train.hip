@@ -218,6 +218,31 @@ __global__ __launch_bounds__(256) void k_adam_rows_bf16(bf16x8* __restrict__ W, 
     }
 }
 
+// Opt-in extension (not the reference's behaviour): Keras Adam with PERSISTENT moments, one step over a whole table.
+//   m += (g - m)(1 - b1);  v += (g g - v)(1 - b2);  w -= (m alpha_t) / (sqrt(v) + eps)
+// - the same fp32 op sequence as adam_fresh, which it equals bit for bit at step 1 with zero moments.
+__global__ __launch_bounds__(256) void k_adam_state_rows(float4* __restrict__ W, const float4* __restrict__ Gr,
+                                                         float4* __restrict__ M, float4* __restrict__ V2, int64_t n4,
+                                                         tmf_adam a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 w = W[i], m = M[i], v = V2[i];
+        const float4 g = Gr[i];
+        float* wp = &w.x;
+        float* mp = &m.x;
+        float* vp = &v.x;
+        const float* gp = &g.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mp[c] = mp[c] + (gp[c] - mp[c]) * a.one_minus_b1;
+            vp[c] = vp[c] + (gp[c] * gp[c] - vp[c]) * a.one_minus_b2;
+            wp[c] = wp[c] - __fdiv_rn(mp[c] * a.alpha, __fsqrt_rn(vp[c]) + a.eps);
+        }
+        W[i] = w;
+        M[i] = m;
+        V2[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Deterministic sum: one 1024-thread block, strided fp64 partials, fixed LDS tree.
 // ---------------------------------------------------------------------------------------------
@@ -363,6 +388,20 @@ extern "C" int tmf_adam_fresh_rows_bf16(void* W, const float* G, int64_t n_rows,
     hipLaunchKernelGGL(k_adam_rows_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<bf16x8*>(W), reinterpret_cast<const float4*>(G), n8, adam);
     return check_launch("tmf_adam_fresh_rows_bf16");
+}
+
+extern "C" int tmf_adam_state_rows_f32(float* W, const float* G, float* M, float* V, int64_t n_rows, int n_components,
+                                       tmf_adam adam, void* stream) {
+    if (n_rows == 0) return TMF_OK;
+    const RowGeom geom = row_geom(n_components);
+    TMF_REQUIRE(geom.ld > 0, "adam_state_rows: unsupported n_components %d", n_components);
+    TMF_REQUIRE(W && G && M && V && n_rows > 0, "adam_state_rows: bad arguments");
+    const int64_t n4 = n_rows * geom.ld / 4;
+    const int64_t want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_adam_state_rows, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(W), reinterpret_cast<const float4*>(G), reinterpret_cast<float4*>(M),
+                       reinterpret_cast<float4*>(V), n4, adam);
+    return check_launch("tmf_adam_state_rows_f32");
 }
 
 extern "C" int tmf_sum_f32(const float* x, int64_t n, double* out, void* stream) {

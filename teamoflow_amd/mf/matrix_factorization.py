@@ -91,6 +91,9 @@ class MatrixFactorization:
         self.verbose = True
         self.factor_dtype = torch.float32  # extension: torch.bfloat16 = bf16 factor storage, fp32 arithmetic
         self.data_parallel = False         # extension: split the users over torch.distributed ranks (teamoflow_amd/dist.py)
+        # extension, OFF by default: 'adam' keeps Adam's moments across epochs.  The reference (and the default here,
+        # 'fresh_adam') builds a new optimizer every epoch (:176), i.e. every step is Adam's first step.
+        self.optimizer = 'fresh_adam'
 
     # ------------------------------------------------------------------------------------------
     # training
@@ -159,7 +162,27 @@ class MatrixFactorization:
         loss_sums = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
         denom = plan.n_pos if wmrb else plan.nnz
         self.loss_history_ = []
+        if self.optimizer not in ('fresh_adam', 'adam'):
+            raise ValueError(f"optimizer={self.optimizer!r}: 'fresh_adam' (the reference's behaviour) or 'adam'")
+        persistent = self.optimizer == 'adam'
+        if persistent:
+            if self.factor_dtype is not torch.float32:
+                raise ValueError("optimizer='adam' (persistent moments) needs float32 factor tables")
+            lib = _lib.get()
+            gU, gV = torch.empty_like(st.U), torch.empty_like(st.V)
+            mom = [torch.zeros_like(st.U), torch.zeros_like(st.U), torch.zeros_like(st.V), torch.zeros_like(st.V)]
+
         def run_epoch(epoch, out):
+            if persistent:  # raw gradients of both sides from the pre-update tables, then one Adam step with state, in place
+                a = lib.tmf_adam_step(float(lr), epoch + 1)
+                if wmrb:
+                    _engine.epoch_wmrb(st, a, c, out, _lib.EPI_GRAD, gV, None, _lib.EPI_GRAD, gU)
+                else:
+                    _engine.epoch_mse(st, a, out, _lib.EPI_GRAD, gV, None, _lib.EPI_GRAD, gU)
+                for W, G, M, V2 in ((st.U, gU, mom[0], mom[1]), (st.V, gV, mom[2], mom[3])):
+                    _lib.check(lib.tmf_adam_state_rows_f32(_lib.ptr(W), _lib.ptr(G), _lib.ptr(M), _lib.ptr(V2), W.shape[0],
+                                                           self.n_components, a, _lib.stream_ptr()), lib)
+                return
             if wmrb:
                 _engine.epoch_wmrb(st, adam, c, out)
             else:
@@ -170,7 +193,7 @@ class MatrixFactorization:
         # epochs into one hipGraph and replay it - the per-launch host cost disappears from the loop.
         work = plan.nnz + (plan.n_users * wplan.S if wmrb else 0)
         G = min(epochs - epochs % 2, GRAPH_EPOCHS)
-        use_graph = G >= 4 and work <= GRAPH_MAX_WORK and os.environ.get('TMF_NO_GRAPH') is None
+        use_graph = G >= 4 and work <= GRAPH_MAX_WORK and os.environ.get('TMF_NO_GRAPH') is None and not persistent
         torch.cuda.synchronize(dev)
         t0 = timeit.default_timer()
         self.plan_seconds_ = t0 - t_plan  # extension: index structures + table set-up of this fit (once, not per epoch)
