@@ -432,15 +432,18 @@ class MatrixFactorization:
                      'Number of Users': 'n_users', 'Number of Items': 'n_items', 'Number of Samples': 'n_samples',
                      'Generate Sample': 'generate_sample'}
 
-    def save(self, path, include_samples=True):
-        """Extension: save_model()'s two dicts plus the tables in ONE file (torch.save).  The
-        plug-in objects are pickled as they are; ``include_samples=False`` leaves the [m, S] negative table out."""
-        _save_to_disk(self, path, include_samples)
+    def save(self, path, include_samples=True, allow_pickle=False):
+        """Extension: save_model()'s two dicts plus the tables in ONE file (torch.save).  The built-in
+        plug-ins are stored as plain data (class name + constructor state), so the file loads with
+        ``torch.load(weights_only=True)``; a user-defined plug-in object can only be stored pickled
+        (``allow_pickle=True`` here AND in ``load``).  ``include_samples=False`` leaves the [m, S] negative table out."""
+        _save_to_disk(self, path, include_samples, allow_pickle)
 
     @classmethod
-    def load(cls, path, device=None):
-        """Inverse of ``save``: a model ready for predict / recall_at_k / a further fit."""
-        return _load_from_disk(cls, path, device)
+    def load(cls, path, device=None, allow_pickle=False):
+        """Inverse of ``save``: a model ready for predict / recall_at_k / a further fit.  ``allow_pickle=True`` unpickles
+        arbitrary objects from the file - only for files you wrote yourself."""
+        return _load_from_disk(cls, path, device, allow_pickle)
 
     @classmethod
     def from_saved(cls, config):
@@ -449,28 +452,73 @@ class MatrixFactorization:
         return cls(**{cls._DISPLAY_KEYS.get(k, k): v for k, v in config.items()})
 
 
-def _save_to_disk(model, path, include_samples=True):
+_PLUGIN_KEYS = ('User Embedding', 'Item Embedding', 'Loss', 'User Initialization', 'Item Initialization')
+
+
+def _builtin_plugins():
+    from . import embedding_graphs, initializer_graphs, loss_graphs
+    out = {}
+    for mod in (embedding_graphs, initializer_graphs, loss_graphs):
+        for name in dir(mod):
+            obj = getattr(mod, name)
+            if isinstance(obj, type) and obj.__module__ == mod.__name__ and not name.startswith('_'):
+                out[name] = obj
+    return out
+
+
+def _encode_plugin(obj, allow_pickle):
+    """Built-in plug-in -> {'plugin': class name, 'state': plain data}; anything else only as a pickled object."""
+    cls = _builtin_plugins().get(type(obj).__name__)
+    if cls is not None and type(obj) is cls:
+        state = {}
+        for k, v in vars(obj).items():
+            if torch.is_tensor(v) or isinstance(v, np.ndarray):
+                v = torch.as_tensor(v).detach().cpu()
+            elif not isinstance(v, (int, float, bool, str, type(None))):
+                raise TypeError(f'{type(obj).__name__}.{k} of type {type(v).__name__} cannot be stored as plain data')
+            state[k] = v
+        return {'plugin': type(obj).__name__, 'state': state}
+    if not allow_pickle:
+        raise TypeError(f'{type(obj).__name__} is not a built-in plug-in: pass allow_pickle=True to store it pickled')
+    return {'pickled': obj}
+
+
+def _decode_plugin(entry):
+    if 'pickled' in entry:
+        return entry['pickled']
+    cls = _builtin_plugins()[entry['plugin']]
+    obj = cls.__new__(cls)
+    for k, v in entry['state'].items():
+        setattr(obj, k, v)
+    return obj
+
+
+def _save_to_disk(model, path, include_samples=True, allow_pickle=False):
     config, results = model.save_model()
-    blob = {'format': 'teamoflow_amd.mf/1', 'config': config,
+    config = {k: (_encode_plugin(v, allow_pickle) if k in _PLUGIN_KEYS else v) for k, v in config.items()}
+    blob = {'format': 'teamoflow_amd.mf/2', 'config': config,
             'user_embedding': None if model.user_embedding is None else model.user_embedding.detach().float().cpu(),
             'item_embedding': None if model.item_embedding is None else model.item_embedding.detach().float().cpu(),
             'factor_dtype': str(model.factor_dtype).replace('torch.', ''),
-            'loss_history': list(getattr(model, 'loss_history_', []) or []),
+            'optimizer': getattr(model, 'optimizer', 'fresh_adam'),
+            'loss_history': [float(x) for x in (getattr(model, 'loss_history_', []) or [])],
             'random_ind': (torch.as_tensor(model.random_ind).cpu() if include_samples and model.random_ind is not None else None)}
     torch.save(blob, path)
 
 
-def _load_from_disk(cls, path, device=None):
-    blob = torch.load(path, map_location='cpu', weights_only=False)
-    if blob.get('format') != 'teamoflow_amd.mf/1':
+def _load_from_disk(cls, path, device=None, allow_pickle=False):
+    blob = torch.load(path, map_location='cpu', weights_only=not allow_pickle)
+    if blob.get('format') != 'teamoflow_amd.mf/2':
         raise ValueError(f'{path}: not a teamoflow_amd model file')
-    cfg = dict(blob['config'])
+    cfg = {k: (_decode_plugin(v) if k in _PLUGIN_KEYS else v) for k, v in blob['config'].items()}
+    generate = cfg['Generate Sample']
     cfg['Generate Sample'] = False          # the table comes from the file (or is absent), never redrawn
     model = cls.from_saved(cfg)
-    model.generate_sample = blob['config']['Generate Sample']
+    model.generate_sample = generate
     dev = default_device() if device is None else torch.device(device)
     dt = getattr(torch, blob['factor_dtype'])
     model.factor_dtype = dt
+    model.optimizer = blob.get('optimizer', 'fresh_adam')
     for name in ('user_embedding', 'item_embedding'):
         t = blob[name]
         setattr(model, name, None if t is None else t.to(device=dev, dtype=dt))

@@ -128,3 +128,24 @@ def test_save_and_load_roundtrip(tmp_path):
     assert back.loss_history_ == [3.0, 2.5]
     model.save(path, include_samples=False)
     assert MatrixFactorization.load(path, device='cpu').random_ind is None
+    # the file holds plain data only: it loads with weights_only=True (no code runs on load) ...
+    blob = torch.load(path, map_location='cpu', weights_only=True)
+    assert blob['config']['Loss'] == {'plugin': 'WMRBLoss', 'state': {}}
+    # ... a FixedInitializer keeps its matrix, and a user-defined plug-in needs the explicit pickle opt-in on both sides
+    from teamoflow.mf.initializer_graphs import FixedInitializer, Initializer
+    model.item_weight_graph = FixedInitializer(np.arange(6, dtype=np.float32).reshape(3, 2))
+    model.save(path)
+    again = MatrixFactorization.load(path, device='cpu')
+    assert torch.equal(torch.as_tensor(again.item_weight_graph.weights), torch.arange(6.).reshape(3, 2))
+    model.user_weight_graph = _CustomInit()
+    with pytest.raises(TypeError):
+        model.save(path)
+    model.save(path, allow_pickle=True)
+    with pytest.raises(Exception):
+        MatrixFactorization.load(path, device='cpu')
+    assert isinstance(MatrixFactorization.load(path, device='cpu', allow_pickle=True).user_weight_graph, _CustomInit)
+
+
+class _CustomInit:
+    def initialize_weights(self, n_features, n_components):
+        return torch.zeros(n_features, n_components)
