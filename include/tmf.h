@@ -253,7 +253,7 @@ int tmf_adam_fresh_rows_bf16(void* W, const float* G, int64_t n_rows, int n_comp
 
 /* K7+K8 fused: out_idx[u, :k] = top-k (value desc, index asc) of A[u, :r] . B[:, :r]^T over all n items,
  * without materialising the [m, n] scores (recall_at_k / retrieve_user_recs, matrix_factorization.py:236-248,
- * :424-438, at catalog sizes where the dense matrix does not fit).  Supports k <= 64 and r <= 128; returns
+ * :424-438, at catalog sizes where the dense matrix does not fit).  Supports k <= 64 and r <= 256; returns
  * TMF_E_UNSUPPORTED otherwise (callers then score block-wise with tmf_predict_gemm_f32 + tmf_topk_stable_f32). */
 int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
                          int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,

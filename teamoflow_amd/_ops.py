@@ -42,7 +42,7 @@ def predict_gemm(user_embedding, item_embedding, out=None):
     return out
 
 
-FUSED_MAX_K, FUSED_MAX_K_BF16, FUSED_MAX_R, FUSED_MAX_R_BF16 = 64, 32, 128, 256
+FUSED_MAX_K, FUSED_MAX_K_BF16, FUSED_MAX_R, FUSED_MAX_R_BF16 = 64, 32, 256, 256
 SORT_MAX_ELEMS = 1 << 29   # elements ranked per call of the wide-row path (2 GB of keys + 2 GB of ids, twice)
 
 
@@ -66,7 +66,7 @@ def fused_topk_supported(user_embedding, item_embedding, k):
 
 def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False):
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
-    fp32 tables: exact-fp32 MFMA, k <= 64, width <= 128.  bf16 tables (both operands): bf16 MFMA with fp32
+    fp32 tables: exact-fp32 MFMA, k <= 64, width <= 256.  bf16 tables (both operands): bf16 MFMA with fp32
     accumulation, k <= 32, width <= 256.  See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
     if torch.is_tensor(user_embedding) and torch.is_tensor(item_embedding) and \

@@ -375,7 +375,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 2: K % 4 == 0 and V < 4 GB (buffer loads, constant per-thread offsets), 1: K % 4 == 0 (branch-free), 0: any K
 template <int NCH, int MODE>  // K_PAD = 32 * NCH
-__global__ __launch_bounds__(256, 2) void k_predict_topk(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const float* __restrict__ A, const float* __restrict__ B,
                                                          int64_t m, int64_t n, int K, int64_t lda, int64_t ldb, int k,
                                                          int clamp, int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_val) {
@@ -674,14 +674,15 @@ extern "C" int tmf_predict_topk_f32(const float* A, const float* B, int64_t m, i
                     ((uintptr_t)B % 16 == 0), "predict_topk: operands must be 16-byte aligned with ld %% 4 == 0");
     TMF_REQUIRE(k >= 1 && k <= n, "predict_topk: k=%d must be in [1, n=%lld]", k, (long long)n);
     TMF_REQUIRE(n < ((int64_t)1 << 31), "predict_topk: too many items");
-    if (k > tmf::FMAXK || r > 128) {
-        tmf::set_error("predict_topk: fused kernel supports k <= %d and n_components <= 128 (got k=%d, r=%d)", tmf::FMAXK, k, r);
+    if (k > tmf::FMAXK || r > 256) {
+        tmf::set_error("predict_topk: fused kernel supports k <= %d and n_components <= 256 (got k=%d, r=%d)", tmf::FMAXK, k, r);
         return TMF_E_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
     if (r <= 32) return tmf::launch_predict_topk<1>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
     if (r <= 64) return tmf::launch_predict_topk<2>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
-    return tmf::launch_predict_topk<4>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+    if (r <= 128) return tmf::launch_predict_topk<4>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);
+    return tmf::launch_predict_topk<8>(A, B, m, n, r, lda, ldb, k, clamp_negatives, out_idx, out_val, s);  // 128 A registers per lane
 }
 
 // =============================================================================================

@@ -389,7 +389,8 @@ def test_full_ranking_and_large_k_on_a_real_catalog(tm):
 def test_fused_predict_topk_matches_materialised_and_oracle(tm):
     from oracle import sparse_ref as S
     rng = np.random.default_rng(9)
-    for m, n, r in [(1, 5, 3), (100, 50, 5), (130, 257, 32), (257, 1000, 64), (300, 4099, 128), (64, 128, 100)]:
+    for m, n, r in [(1, 5, 3), (100, 50, 5), (130, 257, 32), (257, 1000, 64), (300, 4099, 128), (64, 128, 100), (200, 1500, 256),
+                    (70, 900, 130)]:
         U = rng.standard_normal((m, r)).astype(np.float32)
         V = rng.standard_normal((n, r)).astype(np.float32)
         if n > 200:
@@ -756,9 +757,9 @@ def test_c_abi_error_codes_and_messages(tm):
     assert rc == -1 and b'workspace' in lib.tmf_last_error()
     rc = lib.tmf_predict_topk_f32(tm.lib.ptr(x), tm.lib.ptr(x), 8, 8, 8, 8, 8, 33, 0, tm.lib.ptr(out), None, s)  # k > 32
     assert rc == -1 or rc == -3
-    big = torch.zeros(4, 132, device='cuda')
-    rc = lib.tmf_predict_topk_f32(tm.lib.ptr(big), tm.lib.ptr(big), 4, 4, 130, 132, 132, 2, 0, tm.lib.ptr(out), None, s)
-    assert rc == -3 and b'n_components <= 128' in lib.tmf_last_error()                            # unsupported width
+    big = torch.zeros(4, 260, device='cuda')
+    rc = lib.tmf_predict_topk_f32(tm.lib.ptr(big), tm.lib.ptr(big), 4, 4, 258, 260, 260, 2, 0, tm.lib.ptr(out), None, s)
+    assert rc == -3 and b'n_components <= 256' in lib.tmf_last_error()                            # unsupported width
     rc = lib.tmf_predict_gemm_f32(None, tm.lib.ptr(x), tm.lib.ptr(x), 8, 8, 8, 8, 8, 8, s)
     assert rc == -1
     seg = tm.lib.Segments(0, 0, 0, 0, 5, 1024, 0)                                                 # null arrays, nseg = 5
@@ -816,7 +817,7 @@ def test_randomized_fused_topk(tm, seed):
     from oracle import sparse_ref as S
     rng = np.random.default_rng(7000 + seed)
     m, n = int(rng.integers(1, 400)), int(rng.integers(1, 3000))
-    r = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128]))
+    r = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128, 129, 200, 256]))
     k = int(min(n, rng.choice([1, 2, 5, 10, 17, 32, 50, 64])))
     span = int(rng.choice([1, 2, 4]))
     U = rng.integers(-span, span + 1, (m, r)).astype(np.float32)
