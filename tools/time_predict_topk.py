@@ -1,4 +1,5 @@
-"""Fused top-k predict throughput: python tools/time_predict_topk.py [r ...]   (fp32 tables, 262144 users x 100000 items)"""
+"""Fused top-k predict throughput: python tools/time_predict_topk.py [r ...]   (fp32 tables, 262144 users x 100000 items;
+TMF_TIME_K=10 restricts the k values)"""
 import os
 import sys
 import time
@@ -10,7 +11,7 @@ from teamoflow_amd import _ops  # noqa: E402
 
 dev = 'cuda'
 for r in [int(a) for a in sys.argv[1:]] or [128]:
-    for k in (10, 64):
+    for k in [int(x) for x in os.environ.get('TMF_TIME_K', '10,64').split(',')]:
         m, n = 262144, 100000
         U = torch.randn(m, r, device=dev) * 0.1
         V = torch.randn(n, r, device=dev) * 0.1
