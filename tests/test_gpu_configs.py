@@ -135,3 +135,81 @@ def test_wmrb_subgradient_at_exact_ties(tm, monkeypatch, slices):  # noqa: F811
     strict = S.wmrb_terms(U0.astype(np.float64), V0.astype(np.float64), idx, val.astype(np.float64), R, n, S_)
     act_strict = (((1.0 - strict['p'])[:, None] + strict['sp'][idx[pos, 0]]) > 0).sum(1)
     assert (act_strict != (xks >= 0).sum(1)).any()
+
+
+def hinge_reference(rowptr, val, p, sp, c):
+    """loss_graphs.py:80-88 for given scores, in fp64 with the fp32 hinge arguments the reference forms:
+    x = fl(fl(1 - p_k) + sp[u, s]); M = c sum max(x, 0); w = c / (1 + M); delta = -w #{x >= 0}; D[u, s] = sum_k w [x >= 0]."""
+    m, S = sp.shape
+    delta = np.zeros(len(p))
+    D = np.zeros((m, S))
+    loss = np.zeros(m)
+    for u in range(m):
+        for k in range(rowptr[u], rowptr[u + 1]):
+            if not val[k] > 0:
+                continue
+            x = (np.float32(1) - np.float32(p[k])) + sp[u].astype(np.float32)
+            act = x >= 0
+            M = c * np.maximum(x.astype(np.float64), 0).sum()
+            w = c / (1 + M)
+            loss[u] += np.log1p(M)
+            delta[k] = -w * act.sum()
+            D[u] += w * act
+    return delta, D, loss
+
+
+@pytest.mark.parametrize('case', ['chunks', 'ties', 'wide', 'tiny', 'degenerate'])
+def test_hinge_kernel_alone(tm, case):  # noqa: F811
+    """tmf_wmrb_hinge2 through the C ABI on scores made up here: chunk boundaries (255 / 256 / 511 interactions of a
+    user), sample counts that are no multiple of 64 and go beyond the two register-held tiles, many equal scores and
+    thresholds (every bucket of the rank histogram, atomics landing on one address), users without positives, empty users,
+    scores of very different magnitude (the fixed-point scale).  Against an fp64 evaluation of the reference's formula."""
+    import ctypes
+    rng = np.random.default_rng({'chunks': 1, 'ties': 2, 'wide': 3, 'tiny': 4, 'degenerate': 5}[case])
+    lib = tm.lib.get()
+    if case == 'chunks':
+        degs, S_ = [0, 1, 254, 255, 256, 257, 510, 511, 700, 3], 300
+    elif case == 'ties':
+        degs, S_ = [40, 300, 5, 64, 65], 1024
+    elif case == 'wide':
+        degs, S_ = [10, 270, 33], 2500            # 5 tiles of 512: ranks are searched twice
+    elif case == 'tiny':
+        degs, S_ = [3, 1, 2, 70], 1
+    else:
+        degs, S_ = [20, 20, 20, 20, 0, 6], 130
+    m = len(degs)
+    rowptr = np.concatenate([[0], np.cumsum(degs)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    val = rng.integers(-1, 5, nnz).astype(np.float32)           # ~1/3 of the entries are not positives
+    p = rng.standard_normal(nnz).astype(np.float32)
+    sp = rng.standard_normal((m, S_)).astype(np.float32)
+    if case == 'ties':      # few distinct values on both sides: exact ties everywhere, buckets with hundreds of samples
+        p = rng.integers(-2, 3, nnz).astype(np.float32) * 0.5
+        sp = rng.integers(-3, 3, (m, S_)).astype(np.float32) * 0.5
+    if case == 'degenerate':
+        sp[0] = 5.0                                   # every sample active for every positive ("all" bucket only)
+        sp[1] = -50.0                                 # none active: M = 0, w = c, delta = 0, D = 0
+        val[rowptr[2]:rowptr[3]] = -1.0               # a user without positives
+        p[rowptr[3]:rowptr[4]] = 0.25                 # all thresholds equal
+        sp[3, ::2] *= 1e-6                            # magnitudes 1e-6 .. 1 in one row
+        sp[5] = rng.standard_normal(S_).astype(np.float32) * 1e4
+        p[rowptr[5]:rowptr[6]] = rng.standard_normal(6).astype(np.float32) * 1e4
+    c = 37.5
+    t = lambda a, dt: torch.tensor(a, dtype=dt, device='cuda')  # noqa: E731
+    d_rowptr, d_val, d_p, d_sp = t(rowptr, torch.int64), t(val, torch.float32), t(p, torch.float32), t(sp, torch.float32)
+    delta = torch.full((max(nnz, 1),), 7.0, device='cuda')
+    D = torch.full((m, S_), 7.0, device='cuda')
+    loss = torch.full((m,), 7.0, device='cuda')
+    for _ in range(2):      # twice: the second launch must reproduce the bits of the first
+        tm.lib.check(lib.tmf_wmrb_hinge2(tm.lib.ptr(d_rowptr), tm.lib.ptr(d_val), tm.lib.ptr(d_p), tm.lib.ptr(d_sp),
+                                         ctypes.c_int32(m), ctypes.c_int32(S_), c, tm.lib.ptr(delta), tm.lib.ptr(D),
+                                         tm.lib.ptr(loss), tm.lib.stream_ptr()), lib)
+        torch.cuda.synchronize()
+        got = (delta[:nnz].cpu().numpy().copy(), D.cpu().numpy().copy(), loss.cpu().numpy().copy())
+        if _ == 0:
+            first = got
+    assert all(np.array_equal(a, b) for a, b in zip(first, got))
+    r_delta, r_D, r_loss = hinge_reference(rowptr, val, p, sp, c)
+    assert rel_err(got[0], r_delta) < 1e-5 and rel_err(got[1], r_D) < 1e-5
+    assert np.abs(got[2] - r_loss).max() <= 1e-5 * max(np.abs(r_loss).max(), 1e-30)
+    assert (got[0][~(val > 0)] == 0).all()
