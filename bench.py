@@ -604,8 +604,7 @@ def main():
         # the same epochs through the public API (fit re-initialises, so it runs warmup + steps epochs from the same start)
         engine_ms = (elapsed + warm_elapsed) / (args.steps + args.warmup) * 1e3
         del Ue, Ve
-        wl.st = None
-        torch.cuda.empty_cache()
+        wl.st = None   # its memory stays in torch's caching allocator: the model's tables and plans reuse it (no hipMalloc in plan_seconds)
         out['api_fit'] = api_fit(dev, wl, args, args.steps + args.warmup)
         out['api_fit'].update(engine_ms_per_epoch_same_epochs=engine_ms,
                               api_over_engine=out['api_fit']['ms_per_epoch'] / engine_ms)
