@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TMF_VERSION 200 /* 0.2.0 */
+#define TMF_VERSION 201 /* 0.2.1 */
 
 #define TMF_OK 0
 #define TMF_E_INVALID (-1)   /* bad argument (null pointer, unsupported rank, size mismatch) */
@@ -167,6 +167,10 @@ typedef struct tmf_slice_lists {
     const int32_t* col;       /* [nnz] */
     const int32_t* pos_off;   /* [n_users, n_slices + 1] (tmf_slice_offsets on col with rowptr) */
     int32_t n_users, n_samples, n_slices;
+    /* Window of the catalog a launch covers (item-row-sharded V, one window of rows resident at a time): slices
+     * [slice_begin, slice_begin + slice_count) and the V pointer of the call addresses item row `item_base` (the first row
+     * of the window).  All three 0 = the whole catalog. */
+    int32_t slice_begin, slice_count, item_base;
 } tmf_slice_lists;
 /* Kernels, called in this order on one stream (tables float (_f32) or bf16 (_bf16) rows as void*; sp / p / D / delta /
  * part / w_ent are fp32):
@@ -175,7 +179,9 @@ typedef struct tmf_slice_lists {
  *   tmf_wmrb_gradu3_*   part[slice][u] = sum_{s in slice} D[u, s] V[R_sorted[u, s]] + sum_{k in slice} delta_k V[col[k]]
  *                       per_slice_launches = 0: one launch, part is [n_slices * n_users, ld], finish gets n_slices;
  *                       per_slice_launches = 1: one launch per slice adding into ONE [n_users, ld] layer (memory-light;
- *                       finish is then called with n_slices = 1)
+ *                       finish is then called with n_slices = 1); the first slice launched overwrites the layer;
+ *                       per_slice_launches = 2: the same, but the first slice launched adds to the layer as well (the
+ *                       later windows of a windowed pass)
  *   tmf_wmrb_finish_*   U_out[u] = epilogue(sum_slice part[slice][u]) */
 int tmf_wmrb_scores3_f32(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,
                          int n_components, void* stream);

@@ -85,6 +85,35 @@ class SegmentTable:
         self.n_long = int(long_rows.numel())
         self._c = None
 
+    @classmethod
+    def of_rows(cls, rowptr, rows, out_row, n_out, chunk=DEFAULT_CHUNK):
+        """Segments of a SUBSET of the list rows of ``rowptr`` (int64 ids ``rows``, any order), every one with a slab slot;
+        ``out_row[i]`` in [0, n_out) is the output row the partial sums of list row ``rows[i]`` belong to.  One window of
+        an item-row-sharded pass: the lists of the window's items, output rows relative to the window."""
+        self = cls.__new__(cls)
+        dev = rowptr.device
+        lens = rowptr[rows + 1] - rowptr[rows]
+        nch = torch.clamp((lens + (chunk - 1)) // chunk, min=1)
+        nseg = int(nch.sum())
+        seg_first = _excl_cumsum(nch)
+        sel = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), nch, output_size=nseg)
+        seg_chunk = torch.arange(nseg, device=dev) - seg_first[sel]
+        seg_out = out_row[sel]
+        order = torch.sort(seg_out, stable=True)[1]
+        seg_slab = torch.empty(nseg, dtype=torch.int64, device=dev)
+        seg_slab[order] = torch.arange(nseg, device=dev)
+        self.n_slab = nseg
+        self.long_slab_beg = _excl_cumsum(torch.bincount(seg_out, minlength=n_out))
+        self.rows, self.chunk, self.nseg, self.row_mod = int(rows.numel()), int(chunk), nseg, 0
+        self.rowptr = rowptr
+        self.seg_row = rows[sel].to(torch.int32)
+        self.seg_chunk = seg_chunk.to(torch.int32)
+        self.seg_slab = seg_slab.to(torch.int32)
+        self.long_rows = torch.arange(n_out, device=dev, dtype=torch.int32)
+        self.n_long = int(n_out)
+        self._c = None
+        return self
+
     def cstruct(self):
         if self._c is None:
             self._c = _lib.Segments(self.rowptr.data_ptr(), self.seg_row.data_ptr(), self.seg_chunk.data_ptr(),
@@ -225,12 +254,12 @@ class WmrbPlan:
     Sliced pass (``sliced``): ``R`` holds every user's negatives in ascending item order, ``slice_off`` / ``pos_off`` the first
     negative / interaction of every item slice."""
 
-    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128):
+    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128, sliced=None, item_lists=True):
         dev = R.device
         m, S = R.shape
         nnz, n = plan.nnz, plan.n_items
         self.S, self.n_slices = S, max(1, int(item_slices))
-        self.sliced = self.n_slices > 1 or not fused_user_pass_fits(S, n_components)
+        self.sliced = bool(sliced) if sliced is not None else (self.n_slices > 1 or not fused_user_pass_fits(S, n_components))
         C = self.user_chunks = max(1, int(user_chunks))
         E = nnz + m * S
         if E >= 2 ** 31:
@@ -292,7 +321,9 @@ class WmrbPlan:
             ent_id = ent_id.to(torch.int32)
         self.rowptr_e = rowptr[:C * n + 1].contiguous()  # the row behind them holds the stored values <= 0: never read
         self.ent_w = ent_id
-        if C > 1:
+        if not item_lists:
+            self.seg_e = None   # the caller cuts the lists into windows itself (SegmentTable.of_rows)
+        elif C > 1:
             out_row = torch.arange(C * n, device=dev) % n
             self.seg_e = SegmentTable(self.rowptr_e, chunk, out_row=out_row, n_out=n)
         else:
@@ -309,6 +340,13 @@ class WmrbPlan:
             self._lists = _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(),
                                           plan.col_u.data_ptr(), self.pos_off.data_ptr(), m, S, self.n_slices)
         return ctypes.byref(self._lists)
+
+    def window_lists(self, plan, slice_begin, slice_count, item_base):
+        """tmf_slice_lists restricted to slices [slice_begin, +slice_count); the V pointer of the call then holds the rows
+        from item_base on (item-row-sharded V).  The caller keeps the returned struct alive."""
+        m, S = self.R.shape
+        return _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(), plan.col_u.data_ptr(),
+                               self.pos_off.data_ptr(), m, S, self.n_slices, slice_begin, slice_count, item_base)
 
     def D_in_model_order(self):
         """D[u, s] indexed like the model's random_ind (the sliced pass keeps every user's negatives sorted by item)."""

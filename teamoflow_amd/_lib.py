@@ -32,7 +32,8 @@ class Adam(ctypes.Structure):
 class SliceLists(ctypes.Structure):
     _fields_ = [('R_sorted', ctypes.c_void_p), ('slice_off', ctypes.c_void_p), ('rowptr', ctypes.c_void_p),
                 ('col', ctypes.c_void_p), ('pos_off', ctypes.c_void_p), ('n_users', ctypes.c_int32),
-                ('n_samples', ctypes.c_int32), ('n_slices', ctypes.c_int32)]
+                ('n_samples', ctypes.c_int32), ('n_slices', ctypes.c_int32), ('slice_begin', ctypes.c_int32),
+                ('slice_count', ctypes.c_int32), ('item_base', ctypes.c_int32)]
 
 
 class Segments(ctypes.Structure):
@@ -120,7 +121,7 @@ def load_library():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.tmf_version() < 200:
+    if lib.tmf_version() < 201:
         raise EngineUnavailable('libtmf.so is older than this package')
     _lib = lib
     return lib

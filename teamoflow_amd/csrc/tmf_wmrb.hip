@@ -388,7 +388,7 @@ __device__ __forceinline__ int* slice_stage(char* smem_raw, int gid) {
 template <int G, int NV, typename T, bool GRADU>
 __device__ __forceinline__ void slice_list(int* ids, float* dst, const int32_t* __restrict__ list, int beg, int end,
                                            const T* __restrict__ V, const Frag<NV>& x, Frag<NV>& acc,
-                                           float* __restrict__ out, const float* __restrict__ wts, int g) {
+                                           float* __restrict__ out, const float* __restrict__ wts, int g, int safe) {
     constexpr int kStageTile = Stage<G>::tile;
     for (int t0 = beg; t0 < end; t0 += kStageTile) {
         const int cnt = (end - t0 < kStageTile) ? end - t0 : kStageTile;
@@ -413,7 +413,7 @@ __device__ __forceinline__ void slice_list(int* ids, float* dst, const int32_t* 
                 bool want = e < cnt;
                 d[t] = 0.f;
                 if (GRADU && want) { d[t] = wv[t]; want = d[t] != 0.f; }
-                load_raw<G, NV>(raw[t], V, want ? idv[t] : 0, g);
+                load_raw<G, NV>(raw[t], V, want ? idv[t] : safe, g);  // `safe`: a row that is resident (first of the window)
             }
 #pragma unroll
             for (int t = 0; t < kUnrollW; ++t) {
@@ -445,7 +445,16 @@ struct SliceLists {
     const int32_t* poff;     // [n_users, n_slices + 1] first interaction of every slice, relative to rowptr[u]
     int n_slices, S;
     int64_t n_users, n_groups;
+    int sl0, nsl;            // slices [sl0, sl0 + nsl) are covered by this launch ...
+    int item_base;           // ... and V points at item row item_base (windowed V: only these rows are resident)
 };
+
+// V rebased so that global item ids index it (rows outside the window are never touched: every id of the launched slices
+// lies inside, idle lanes read row item_base)
+template <int G, int NV, typename T>
+__device__ __forceinline__ const T* window_base(const T* V, int item_base) {
+    return V - (int64_t)item_base * (4 * G * NV);
+}
 
 template <int G, int NV, typename T>
 __global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T* __restrict__ U, const T* __restrict__ V,
@@ -456,35 +465,37 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
     int* ids = slice_stage<G>(smem_raw, gid);
     float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
-    const int64_t sl = blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
+    const int64_t sl = a.sl0 + blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
     const int64_t ubeg = grp * kSliceUsers;
     const int64_t uend = (ubeg + kSliceUsers < a.n_users) ? ubeg + kSliceUsers : a.n_users;
+    V = window_base<G, NV, T>(V, a.item_base);
     for (int64_t u = ubeg + gid; u < uend; u += NGB) {
         const int64_t o = u * (a.n_slices + 1) + sl;
         const int nb = a.off[o], ne = a.off[o + 1], pb = a.poff[o], pe = a.poff[o + 1];
         if (nb == ne && pb == pe) continue;
         Frag<NV> x, none;
         load_row<G, NV>(x, U, u, g);
-        slice_list<G, NV, T, false>(ids, dst, a.R + u * (int64_t)a.S, nb, ne, V, x, none, sp + u * (int64_t)a.S, nullptr, g);
+        slice_list<G, NV, T, false>(ids, dst, a.R + u * (int64_t)a.S, nb, ne, V, x, none, sp + u * (int64_t)a.S, nullptr, g,
+                                    a.item_base);
         const int64_t rb = a.rowptr[u];
-        slice_list<G, NV, T, false>(ids, dst, a.col + rb, pb, pe, V, x, none, p + rb, nullptr, g);
+        slice_list<G, NV, T, false>(ids, dst, a.col + rb, pb, pe, V, x, none, p + rb, nullptr, g, a.item_base);
     }
 }
 
-// slice_first >= 0: this launch covers ONE slice (slice_first) and adds into the single-layer `part`
-// (plain read-modify-write; launches of consecutive slices are ordered by the stream).
+// slice_first >= 0: this launch covers ONE slice (slice_first) and writes (accumulate == 1) or adds (2) into the
+// single-layer `part` (plain read-modify-write; launches of consecutive slices are ordered by the stream).
 template <int G, int NV, typename T>
 __global__ __launch_bounds__(kThreads) void k_wmrb_gradu3(SliceLists a, const T* __restrict__ V, const float* __restrict__ D,
                                                           const float* __restrict__ delta, float* __restrict__ part,
-                                                          int slice_first) {
+                                                          int slice_first, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NG = 64 / G, NGB = NG * kWaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
     int* ids = slice_stage<G>(smem_raw, gid);
     float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
-    const int64_t sl = (slice_first >= 0) ? slice_first : blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
-    const int accumulate = slice_first < 0 ? 0 : (slice_first == 0 ? 1 : 2);
+    const int64_t sl = (slice_first >= 0) ? slice_first : a.sl0 + blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
+    V = window_base<G, NV, T>(V, a.item_base);
     const int64_t ubeg = grp * kSliceUsers;
     const int64_t uend = (ubeg + kSliceUsers < a.n_users) ? ubeg + kSliceUsers : a.n_users;
     for (int64_t u = ubeg + gid; u < uend; u += NGB) {
@@ -493,8 +504,8 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_gradu3(SliceLists a, const T*
         Frag<NV> acc, none;
         zero<NV>(acc);
         const int64_t us = u * (int64_t)a.S, rb = a.rowptr[u];
-        slice_list<G, NV, T, true>(ids, dst, a.R + us, nb, ne, V, none, acc, nullptr, D + us, g);
-        slice_list<G, NV, T, true>(ids, dst, a.col + rb, pb, pe, V, none, acc, nullptr, delta + rb, g);
+        slice_list<G, NV, T, true>(ids, dst, a.R + us, nb, ne, V, none, acc, nullptr, D + us, g, a.item_base);
+        slice_list<G, NV, T, true>(ids, dst, a.col + rb, pb, pe, V, none, acc, nullptr, delta + rb, g, a.item_base);
         if (accumulate == 0) {
             store_row_f32<G, NV, T>(acc, part, sl * a.n_users + u, g);
         } else {  // one launch per slice: part is a single [users, ld] layer summed in slice order
@@ -579,7 +590,11 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
     TMF_REQUIRE(l->n_users == 0 || (l->R_sorted && l->slice_off && l->rowptr && l->pos_off), "%s: null list array", what);
     const int64_t groups = ((int64_t)l->n_users + kSliceUsers - 1) / kSliceUsers;
     TMF_REQUIRE(groups * l->n_slices < ((int64_t)1 << 31), "%s: grid too large", what);
-    a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups};
+    const int sl0 = l->slice_begin, nsl = l->slice_count > 0 ? l->slice_count : l->n_slices - sl0;
+    TMF_REQUIRE(sl0 >= 0 && nsl > 0 && sl0 + nsl <= l->n_slices && l->item_base >= 0, "%s: window [%d, +%d) of %d slices, item_base=%d",
+                what, sl0, l->slice_count, l->n_slices, l->item_base);
+    a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups,
+                   sl0, nsl, l->item_base};
     return TMF_OK;
 }
 
@@ -597,7 +612,7 @@ static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const 
     const RowGeom geom = row_geom_of<T>(n_components);
     const size_t lds = slice_lds(geom);
 #define CALL(G_, NV_)                                                                                              \
-    hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.n_slices)), dim3(kThreads), lds, \
+    hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(kThreads), lds, \
                        (hipStream_t)stream, a, (const T*)U, (const T*)V, sp, p)
     TMF_DISPATCH(T, geom, CALL);
 #undef CALL
@@ -613,19 +628,21 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
     TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
     const RowGeom geom = row_geom_of<T>(n_components);
     const size_t lds = slice_lds(geom);
+    TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 2, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
     if (per_slice_launches) {
-        for (int sl = 0; sl < a.n_slices; ++sl) {
+        for (int sl = a.sl0; sl < a.sl0 + a.nsl; ++sl) {
+            const int accumulate = (sl == a.sl0 && per_slice_launches == 1) ? 1 : 2;
 #define CALL(G_, NV_)                                                                                                    \
     hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)a.n_groups), dim3(kThreads), lds, (hipStream_t)stream, a, \
-                       (const T*)V, D, delta, part, sl)
+                       (const T*)V, D, delta, part, sl, accumulate)
             TMF_DISPATCH(T, geom, CALL);
 #undef CALL
         }
         return check_launch("tmf_wmrb_gradu3");
     }
-#define CALL(G_, NV_)                                                                                             \
-    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.n_slices)), dim3(kThreads), lds, \
-                       (hipStream_t)stream, a, (const T*)V, D, delta, part, -1)
+#define CALL(G_, NV_)                                                                                        \
+    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(kThreads), lds, \
+                       (hipStream_t)stream, a, (const T*)V, D, delta, part, -1, 0)
     TMF_DISPATCH(T, geom, CALL);
 #undef CALL
     return check_launch("tmf_wmrb_gradu3");

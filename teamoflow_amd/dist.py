@@ -174,6 +174,202 @@ class DataParallelEpoch:
                          'not overlapped with compute (a few ms against ~100 ms of local passes at C4)')
 
 
+# ------------------------------------------------------------------------------------------------
+# Item-row-sharded V: the table is never resident as a whole (north star: tables beyond one GPU's HBM).
+# ------------------------------------------------------------------------------------------------
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0   # no process group: one rank that owns every row (single-GPU streaming of V, tests)
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
+def _global_rank(group, r):
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+def broadcast_rows(t, owner, group=None):
+    """Broadcast ``t`` from group rank ``owner``; returns a handle whose wait() orders the CURRENT stream after it
+    (RCCL: the collective runs on the communicator's stream, which itself waits for the work already queued on the
+    current stream - so a staging buffer is not overwritten while an earlier kernel still reads it)."""
+    if _world(group)[0] == 1:
+        return _Done()
+    if _staged(group, t):
+        h = t.cpu()
+        dist.broadcast(h, _global_rank(group, owner), group=group)
+        t.copy_(h)
+        return _Done()
+    return dist.broadcast(t, _global_rank(group, owner), group=group, async_op=True)
+
+
+def reduce_rows_sum(t, owner, group=None):
+    """Sum ``t`` over the ranks into rank ``owner``'s tensor (the content elsewhere is unspecified afterwards)."""
+    if _world(group)[0] == 1:
+        return _Done()
+    if _staged(group, t):
+        h = t.cpu()
+        dist.reduce(h, _global_rank(group, owner), op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done()
+    return dist.reduce(t, _global_rank(group, owner), op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+class ItemShardedEpoch:
+    """One epoch with item-row-sharded V.  The padded catalog is cut into T = world * windows_per_rank windows of equal row
+    count; rank g owns windows [g q, (g+1) q) - their rows and their optimiser step - and NO rank ever holds more than its
+    own rows plus two staging windows.  Users stay partitioned as in DataParallelEpoch; U is never communicated.
+
+        walk 1 (WMRB only)   for every window t, in order:   broadcast(V rows of t from their owner)  ->  scores of t
+        hinge                local
+        walk 2               for every window t, in order:   broadcast(V rows of t)  ->  user-gradient partial of t,
+                                                             raw item gradient of t  ->  reduce(sum) into the owner
+        U <- fresh-Adam      local;      V rows <- fresh-Adam on the owner, after its windows were broadcast for the last time
+        all-reduce           2 doubles   (sum of losses, count)
+
+    The broadcast of window t+1 and the reduce of window t-1 are in flight while window t computes (two staging buffers
+    each; the collectives are asynchronous on the RCCL stream).  Sized at the window, not the table: xGMI is point-to-point
+    (7 links x ~153 GB/s per GPU), a broadcast keeps the owner's seven links busy, so one window of w bytes costs ~w / 153 GB/s
+    and the whole table crosses once per walk - overlapped with that walk's compute.
+    ``backend``: V_own(), two_phase, scores_window(t, Vwin), between(), grads_window(t, Vwin, out), finish_users(),
+    adam_rows(W, G) - teamoflow_amd._windowed.WindowedHipBackend on the GPU, the NumPy oracle in tests/test_dist_cpu.py."""
+
+    def __init__(self, backend, local_count, windows_per_rank=1, group=None):
+        self.b, self.group = backend, group
+        self.world, self.rank = _world(group)
+        self.q = int(windows_per_rank)
+        self.T = self.world * self.q
+        own = backend.V_own()
+        if own.shape[0] % self.q:
+            raise ValueError(f'{own.shape[0]} owned rows are not a multiple of windows_per_rank={self.q}')
+        self.rows = own.shape[0] // self.q
+        dev = own.device
+        self.stage = [torch.empty(self.rows, own.shape[1], dtype=own.dtype, device=dev) for _ in range(2)]
+        self.gbuf = [torch.empty(self.rows, own.shape[1], dtype=torch.float32, device=dev) for _ in range(2)]
+        self.g_own = torch.empty(own.shape[0], own.shape[1], dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.local_count = float(local_count)
+        self.bytes = dict(broadcast_per_walk=self.T * self.rows * own.shape[1] * own.element_size(),
+                          reduce=self.T * self.rows * own.shape[1] * 4, walks=2 if backend.two_phase else 1)
+
+    def _fetch(self, t, buf):
+        owner, i = divmod(t, self.q)
+        tensor = self.b.V_own()[i * self.rows:(i + 1) * self.rows] if owner == self.rank else buf
+        return tensor, broadcast_rows(tensor, owner, self.group)
+
+    def _windows(self):
+        nxt = self._fetch(0, self.stage[0])
+        for t in range(self.T):
+            cur, handle = nxt
+            handle.wait()
+            if t + 1 < self.T:
+                nxt = self._fetch(t + 1, self.stage[(t + 1) % 2])
+            yield t, cur
+
+    def step(self):
+        """Returns the global mean loss as a 0-d fp64 tensor."""
+        b = self.b
+        if b.two_phase:
+            for t, Vwin in self._windows():
+                b.scores_window(t, Vwin)
+            b.between()
+        pending = [_Done(), _Done()]
+        for t, Vwin in self._windows():
+            owner, i = divmod(t, self.q)
+            pending[t % 2].wait()           # the reduce that used this staging buffer two windows ago
+            out = self.g_own[i * self.rows:(i + 1) * self.rows] if owner == self.rank else self.gbuf[t % 2]
+            b.grads_window(t, Vwin, out)
+            pending[t % 2] = reduce_rows_sum(out, owner, self.group)
+        for h in pending:
+            h.wait()
+        loss_sum = b.finish_users()
+        b.adam_rows(b.V_own(), self.g_own)   # every window of this epoch has been broadcast: the rows may change now
+        self.stats[0] = loss_sum.reshape(())
+        self.stats[1] = self.local_count
+        if self.world > 1:
+            all_reduce_sum(self.stats, self.group)
+        return self.stats[0] / self.stats[1]
+
+
+def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, windows_per_rank=1, group=None):
+    """``MatrixFactorization.fit`` with item-row-sharded V (``model.shard_items = windows_per_rank``): users are partitioned
+    over the ranks as in ``fit_data_parallel``, the item rows are owned in contiguous blocks and only pass through the
+    other ranks one window at a time (``ItemShardedEpoch``).  Without a process group it is one rank streaming its own
+    table window by window.  Every rank passes the same global inputs (or, with ``model.local_users``, its own users and
+    - ``model.local_items = True`` - only the initial rows of the items it owns).  On return ``user_embedding`` is this
+    rank's user block, ``item_embedding`` its item rows, ``user_block`` / ``item_block`` their global ranges;
+    ``gather_item_embedding`` assembles the catalog where it fits."""
+    from ._windowed import WindowedHipBackend, pad_table, window_geometry
+    from .mf.loss_graphs import WMRBLoss
+    world, rank = _world(group)
+    dev = interactions.device
+    wmrb = isinstance(model.loss_graph, WMRBLoss)
+    q = max(1, int(windows_per_rank))
+    r, dtype = model.n_components, model.factor_dtype
+    ld = _lib.padded_ld(r, dtype)
+    rows, _, n_pad = window_geometry(n_items, world * q, ld, 2 if dtype is torch.bfloat16 else 4)
+    local = getattr(model, 'local_users', None)
+    if local is not None:
+        b, e = int(local[0]), int(local[1])
+        idx, val = interactions.indices, interactions.values
+    else:
+        u = interactions.indices[:, 0]
+        rowptr = _engine._excl_cumsum(torch.bincount(u, minlength=n_users))
+        S = int(model.random_ind.shape[1]) if wmrb else 0
+        bounds = partition_users(rowptr, world, per_user_cost=S)
+        b, e = bounds[rank], bounds[rank + 1]
+        keep = (u >= b) & (u < e)
+        idx = interactions.indices[keep].clone()
+        idx[:, 0] -= b
+        val = interactions.values[keep]
+    R, c = None, 0.0
+    if wmrb:
+        Rall = torch.as_tensor(model.random_ind)
+        want_rows = e - b if local is not None else n_users
+        if Rall.dim() != 2 or Rall.shape[0] != want_rows:
+            raise ValueError(f'random_ind has shape {tuple(Rall.shape)}, expected [{want_rows}, n_samples]')
+        R = (Rall if local is not None else Rall[b:e]).to(device=dev, dtype=torch.int32).contiguous()
+        if R.numel() and (int(R.min()) < 0 or int(R.max()) >= n_items):
+            raise IndexError('random_ind holds item ids outside [0, n_items)')
+        c = model.n_items / model.n_samples
+    i0, i1 = rank * q * rows, (rank + 1) * q * rows          # owned rows of the padded catalog
+    V0 = torch.as_tensor(V0).detach()
+    V_own = torch.zeros(q * rows, ld, dtype=dtype, device=dev)
+    if getattr(model, 'local_items', False):
+        if V0.shape[0] != max(0, min(i1, n_items) - i0):
+            raise ValueError(f'local_items: the item initialiser must return the {max(0, min(i1, n_items) - i0)} rows this rank owns')
+        V_own[:V0.shape[0]] = pad_table(V0, ld, dtype, dev, r)
+    elif i0 < n_items:
+        V_own[:min(i1, n_items) - i0] = pad_table(V0[i0:min(i1, n_items)], ld, dtype, dev, r)
+    U_blk = torch.as_tensor(U0).detach()
+    U_blk = U_blk if local is not None else U_blk[b:e]
+    backend = WindowedHipBackend(U_blk, V_own, idx, val, R, e - b, n_items, world * q, r, 'wmrb' if wmrb else 'mse', c, lr, dtype=dtype)
+    ep = ItemShardedEpoch(backend, backend.n_loss, windows_per_rank=q, group=group)
+    losses = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
+    for epoch in range(epochs):
+        losses[epoch] = ep.step()
+    torch.cuda.synchronize(dev)
+    model.loss_history_ = losses[:epochs].cpu().tolist()
+    model._state, model.user_block, model.item_block = backend, (b, e), (min(i0, n_items), min(i1, n_items))
+    model.user_embedding = backend.U[:, :r]
+    model.item_embedding = V_own[:max(0, min(i1, n_items) - i0), :r]
+    model.user_trainable, model.item_trainable = [model.user_embedding], [model.item_embedding]
+
+
+def gather_item_embedding(model, n_items, group=None):
+    """Full [n_items, r] item table from the owned blocks (for catalogs that fit after all: tests, export)."""
+    world, rank = _world(group)
+    mine = model._state.V_shard[:, :model.n_components].float().contiguous()
+    if world == 1:
+        return mine[:n_items]
+    out = torch.empty(world * mine.shape[0], mine.shape[1], dtype=torch.float32, device=mine.device)
+    all_gather_rows(out, mine, group)
+    return out[:n_items]
+
+
 def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0, group=None):
     """``MatrixFactorization.fit`` across the ranks of an initialised process group (one process per GPU).
 

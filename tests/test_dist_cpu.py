@@ -128,3 +128,124 @@ def test_partition_with_more_ranks_than_users_and_empty_plans():
     for slices in (1, 3):
         w = WmrbPlan(plan, torch.zeros(0, S, dtype=torch.int32), user_chunks=2, item_slices=slices)
         assert w.ent_row.numel() == 0 and w.rowptr_e.tolist() == [0] * (2 * n + 1) and tuple(w.D.shape) == (0, S)
+
+
+# ------------------------------------------------------------------------------------------------
+# Item-row-sharded V (dist.ItemShardedEpoch): no rank holds the table; windows are broadcast from their owner,
+# the item gradient of a window is reduced into its owner, which alone updates those rows.
+# ------------------------------------------------------------------------------------------------
+class WindowedOracleBackend:
+    """Oracle closed forms behind the window interface.  MSE is evaluated window by window from the rows the epoch hands
+    over (it is separable by item).  WMRB couples the items of a user: the windows received in walk 1 are assembled, the
+    closed form is evaluated on the assembled table, and walk 2 checks that every window arrives again unchanged and hands
+    out the matching rows of the item gradient."""
+
+    def __init__(self, U_blk, V_own, idx_local, val, R_blk, n_items, n_samples, lr, loss, rows, T):
+        self.U, self.own = U_blk.copy(), torch.tensor(V_own)
+        self.idx, self.val, self.R = idx_local, val, R_blk
+        self.n_items, self.n_samples, self.lr, self.loss, self.rows, self.T = n_items, n_samples, lr, loss, rows, T
+        self.two_phase = loss == 'wmrb'
+        self.seen = np.zeros((rows * T, U_blk.shape[1]), np.float32)
+        self.log = []
+
+    def V_own(self):
+        return self.own
+
+    def scores_window(self, t, Vwin):
+        self.log.append(('scores', t))
+        self.seen[t * self.rows:(t + 1) * self.rows] = Vwin.numpy()
+
+    def between(self):
+        from oracle import sparse_ref as S
+        self.log.append(('hinge',))
+        self.U_new, _, _, self.terms = S.wmrb_epoch(self.U, self.seen.copy(), self.idx, self.val, self.R, self.n_items,
+                                                    self.n_samples, self.lr)
+        self.loss_sum = float(self.terms['loss'].astype(np.float64).sum())
+
+    def grads_window(self, t, Vwin, out):
+        from oracle import sparse_ref as S
+        self.log.append(('grads', t))
+        lo = t * self.rows
+        if self.loss == 'wmrb':
+            assert np.array_equal(Vwin.numpy(), self.seen[lo:lo + self.rows])     # the owner has not stepped yet
+            out.copy_(torch.tensor(self.terms['gV'][lo:lo + self.rows]))
+            return
+        if t == 0:
+            self.gU, self.loss_sum = np.zeros(self.U.shape, np.float64), 0.0
+        keep = (self.idx[:, 1] >= lo) & (self.idx[:, 1] < lo + self.rows)
+        sub = self.idx[keep].copy()
+        sub[:, 1] -= lo
+        _, _, _, tm = S.mse_epoch(self.U, Vwin.numpy().copy(), sub, self.val[keep], self.lr)
+        self.gU += tm['gU']
+        self.loss_sum += float(tm['loss'].astype(np.float64).sum())
+        out.copy_(torch.tensor(tm['gV'].astype(np.float32)))
+
+    def finish_users(self):
+        from oracle import sparse_ref as S
+        self.U = self.U_new if self.loss == 'wmrb' else S.adam_fresh(self.U, self.gU.astype(np.float32), self.lr)
+        return torch.tensor([self.loss_sum], dtype=torch.float64)
+
+    def adam_rows(self, W_rows, G_rows):
+        from oracle import sparse_ref as S
+        W_rows.copy_(torch.tensor(S.adam_fresh(W_rows.numpy().copy(), G_rows.numpy(), self.lr)))
+
+
+def _sharded_worker(rank, world, port, loss, q, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import sparse_ref as S
+    from teamoflow_amd import dist as tdist
+    rng = np.random.default_rng(1)
+    m, n, r, Sn, lr = 19, 21, 5, 6, 0.05
+    A = (rng.random((m, n)) < 0.3) * rng.integers(1, 6, (m, n))
+    idx = np.argwhere(A != 0)
+    val = A[A != 0].astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, Sn, replace=False) for _ in range(m)])
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(idx[:, 0], minlength=m))])
+    bounds = tdist.partition_users(rowptr, world, per_user_cost=Sn if loss == 'wmrb' else 0)
+    b, e = bounds[rank], bounds[rank + 1]
+    sel = (idx[:, 0] >= b) & (idx[:, 0] < e)
+    idx_l = idx[sel].copy()
+    idx_l[:, 0] -= b
+    T = world * q
+    rows = -(-n // T)
+    V_pad = np.zeros((rows * T, r), np.float32)
+    V_pad[:n] = V0
+    own = V_pad[rank * q * rows:(rank + 1) * q * rows]
+    backend = WindowedOracleBackend(U0[b:e], own, idx_l, val[sel], R[b:e], n, Sn, lr, loss, rows, T)
+    ep = tdist.ItemShardedEpoch(backend, local_count=int(sel.sum()), windows_per_rank=q)
+    losses = [float(ep.step()) for _ in range(3)]
+    U, V = U0.copy(), V0.copy()
+    ref_losses = []
+    for _ in range(3):
+        if loss == 'mse':
+            U, V, l, _ = S.mse_epoch(U, V, idx, val, lr)
+        else:
+            U, V, l, _ = S.wmrb_epoch(U, V, idx, val, R, n, Sn, lr)
+        ref_losses.append(l)
+    V_ref = np.zeros_like(V_pad)
+    V_ref[:n] = V
+    mine = backend.V_own().numpy()
+    lo = rank * q * rows
+    walk = [('scores', t) for t in range(T)] + [('hinge',)] if loss == 'wmrb' else []
+    ok = (np.allclose(losses, ref_losses, rtol=1e-5)
+          and np.abs(backend.U - U[b:e]).max() < 5e-3 * lr + 1e-6
+          and np.abs(mine - V_ref[lo:lo + q * rows]).max() < 5e-2 * lr + 1e-6
+          and np.all(mine[max(0, n - lo):] == 0)                                  # padding rows stay zero
+          and backend.log[:len(walk) + T] == walk + [('grads', t) for t in range(T)]   # every window once per walk, in order
+          and ep.stage[0].shape[0] == rows and len(ep.stage) == 2)                # two staging windows, never the table
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('loss,q', [('mse', 1), ('wmrb', 1), ('mse', 3), ('wmrb', 2)])
+def test_item_sharded_epoch_matches_single_process(loss, q):
+    world = 2
+    port = 29850 + (os.getpid() % 100) + 2 * q + (0 if loss == 'mse' else 1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, port, loss, q, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)), dict(out)

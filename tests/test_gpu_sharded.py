@@ -1,0 +1,186 @@
+"""Item-row-sharded V on the MI355X (teamoflow_amd/dist.py ItemShardedEpoch + _windowed.WindowedHipBackend; SURVEY.md §8e
+"when V no longer fits").  One rank without a process group streams its own table window by window - the same kernels and
+launch sequence every rank of a sharded job runs - and must reproduce the oracle step and the resident fit; two ranks on one
+card (gloo, host-staged collectives) add the window broadcasts and the per-window reduce into the owner."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_step, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+@pytest.fixture(scope='module')
+def tm():
+    from teamoflow_amd import _lib, _windowed
+    from teamoflow_amd.mf import initializer_graphs, loss_graphs, matrix_factorization, sparse
+    _lib.get()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.windowed = _windowed
+    ns.MF = matrix_factorization.MatrixFactorization
+    ns.Fixed = initializer_graphs.FixedInitializer
+    ns.WMRB = loss_graphs.WMRBLoss
+    ns.Sparse = sparse.SparseInteractions
+    ns.eye = sparse.eye
+    return ns
+
+
+def problem(seed, m, n, r, S, density=0.05):
+    rng = np.random.default_rng(seed)
+    A = (rng.random((m, n)) < density) * rng.integers(1, 6, (m, n))
+    A[:, n - 3:] = 0                                   # items nobody interacted with (may still be sampled)
+    idx = np.argwhere(A != 0)
+    val = A[A != 0].astype(np.float32)
+    val[::7] = 0.0                                     # stored zeros: interactions that are not positives
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, S, replace=False) for _ in range(m)])
+    return idx, val, U0, V0, R
+
+
+def fit(tm, U0, V0, idx, val, shape, epochs, lr, loss, R, S, shard, dtype=torch.float32):
+    m, n = shape
+    kw = dict(user_weight_graph=tm.Fixed(U0), item_weight_graph=tm.Fixed(V0))
+    if loss == 'wmrb':
+        kw.update(loss_graph=tm.WMRB(), n_users=m, n_items=n, n_samples=S)
+    model = tm.MF(U0.shape[1], **kw)
+    if loss == 'wmrb':
+        model.random_ind = torch.as_tensor(R)
+    model.verbose, model.shard_items, model.factor_dtype = False, shard, dtype
+    model.fit(epochs, tm.eye(m), tm.eye(n), tm.Sparse(idx, val, shape), lr=lr)
+    return model
+
+
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+@pytest.mark.parametrize('windows,slice_bytes,r', [(1, 4 << 20, 16), (3, 4 << 20, 16), (4, 2048, 40), (7, 600, 128)])
+def test_windowed_step_against_oracle(tm, monkeypatch, loss, windows, slice_bytes, r):
+    """One epoch with the catalog in `windows` windows (several slices per window when slice_bytes is small; the catalog
+    size is not a multiple of the window count) against the fp64 closed form: mean loss to 1e-5, both tables in the step
+    interval - the criterion of the resident path's check_one_step."""
+    from oracle import sparse_ref as S
+    monkeypatch.setattr(tm.windowed, 'WINDOW_SLICE_BYTES', slice_bytes)
+    m, n, Sn, lr = 157, 203, 31, 0.05
+    idx, val, U0, V0, R = problem(windows, m, n, r, Sn)
+    model = fit(tm, U0, V0, idx, val, (m, n), 1, lr, loss, R, Sn, windows)
+    assert model._state.T == windows and model._state.n_pad >= n and model.item_block == (0, n)
+    if slice_bytes < 4096:
+        assert model._state.k > 1                                   # windows of several slices
+    U64, V64 = U0.astype(np.float64), V0.astype(np.float64)
+    sU = sV = None
+    if loss == 'mse':
+        _, _, mean, t = S.mse_epoch(U64, V64, idx, val.astype(np.float64), lr)
+    else:
+        _, _, mean, t = S.wmrb_epoch(U64, V64, idx, val.astype(np.float64), R, n, Sn, lr)
+        sl = S.wmrb_slack(U64, V64, idx, val.astype(np.float64), R, n, Sn)
+        sU, sV = sl['gU'], sl['gV']
+    assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+    assert_step(model.user_embedding.cpu().numpy(), U0, t['gU'], lr, what=f'{loss} U', slack=sU)
+    assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], lr, what=f'{loss} V', slack=sV)
+    assert torch.all(model._state.V_shard[n:] == 0)                # padding rows of the last window never move
+
+
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+def test_windowed_trajectory_equals_resident_fit(tm, loss):
+    """Ten epochs, 5 windows: the loss trajectory of the streamed table follows the resident one (the gradients are summed in
+    window order, so the tables agree at trajectory tolerance, not bitwise) and a rerun is bit-identical."""
+    m, n, r, Sn, lr = 301, 409, 24, 40, 0.02
+    idx, val, U0, V0, R = problem(11, m, n, r, Sn)
+    a = fit(tm, U0, V0, idx, val, (m, n), 10, lr, loss, R, Sn, 5)
+    b = fit(tm, U0, V0, idx, val, (m, n), 10, lr, loss, R, Sn, 0)
+    assert rel_err(a.loss_history_[:3], b.loss_history_[:3]) < 1e-5
+    assert rel_err(a.loss_history_, b.loss_history_) < 1e-3
+    assert float((a.item_embedding - b.item_embedding).abs().max()) <= 2 * 10 * lr
+    assert float(((a.item_embedding - b.item_embedding).abs() < 1e-3).float().mean()) > 0.9
+    again = fit(tm, U0, V0, idx, val, (m, n), 10, lr, loss, R, Sn, 5)
+    assert again.loss_history_ == a.loss_history_ and torch.equal(again.item_embedding, a.item_embedding)
+    assert torch.equal(again.user_embedding, a.user_embedding)
+
+
+def test_windowed_bf16_storage(tm):
+    """bf16 rows in the owned shard and in the staging windows, fp32 gradients: one WMRB step against the closed form on the
+    bf16-rounded tables (tolerance of the resident bf16 test: the update is rounded to bf16 once)."""
+    from oracle import sparse_ref as S
+    m, n, r, Sn, lr = 120, 150, 32, 20, 0.05
+    idx, val, U0, V0, R = problem(5, m, n, r, Sn)
+    rb = lambda x: torch.tensor(x).bfloat16().float().numpy()   # noqa: E731
+    U0b, V0b = rb(U0), rb(V0)
+    model = fit(tm, U0b, V0b, idx, val, (m, n), 1, lr, 'wmrb', R, Sn, 3, dtype=torch.bfloat16)
+    U1, V1, mean, _ = S.wmrb_epoch(U0b.astype(np.float64), V0b.astype(np.float64), idx, val.astype(np.float64), R, n, Sn, lr)
+    assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+    assert model.item_embedding.dtype is torch.bfloat16
+    dU = np.abs(model.user_embedding.float().cpu().numpy() - U1)
+    dV = np.abs(model.item_embedding.float().cpu().numpy() - V1)
+    assert (dU <= 2 ** -8 * np.abs(U1) + 1e-6).mean() > 0.995 and dU.max() <= 2 * lr + 0.01
+    assert (dV <= 2 ** -8 * np.abs(V1) + 1e-6).mean() > 0.995 and dV.max() <= 2 * lr + 0.01
+
+
+def test_window_outside_the_resident_rows_is_never_read(tm, monkeypatch):
+    """The slice kernels get a V pointer that holds ONLY the window (rebased inside the kernel): put every window in its own
+    allocation surrounded by NaN guard rows and run the scores / gradU kernels directly - a read outside the window would
+    poison sp, p or the partial sums."""
+    import ctypes
+    from teamoflow_amd import _engine, _lib
+    lib = _lib.get()
+    monkeypatch.setattr(tm.windowed, 'WINDOW_SLICE_BYTES', 1024)
+    m, n, r, Sn = 90, 131, 20, 17
+    idx, val, U0, V0, R = problem(3, m, n, r, Sn, density=0.1)
+    dev = torch.device('cuda')
+    T = 4
+    be = tm.windowed.WindowedHipBackend(U0, None, torch.tensor(idx, device=dev), torch.tensor(val, device=dev),
+                                        torch.tensor(R, device=dev, dtype=torch.int32), m, n, T, r, 'wmrb', n / Sn, 0.05)
+    Vp = torch.zeros(be.n_pad, be.ld, device=dev)
+    Vp[:n, :r] = torch.tensor(V0, device=dev)
+    guard = 64
+    for t in range(T):
+        box = torch.full((be.rows + 2 * guard, be.ld), float('nan'), device=dev)
+        box[guard:guard + be.rows] = Vp[t * be.rows:(t + 1) * be.rows]
+        be.scores_window(t, box[guard:guard + be.rows])
+    sp_ref = (torch.tensor(U0, device=dev) @ torch.tensor(V0, device=dev).T).gather(1, be.wplan.R.long())
+    assert torch.isfinite(be.sp).all() and torch.allclose(be.sp, sp_ref, rtol=1e-5, atol=1e-6)
+    be.between()
+    out = torch.empty(be.rows, be.ld, device=dev)
+    for t in range(T):
+        box = torch.full((be.rows + 2 * guard, be.ld), float('nan'), device=dev)
+        box[guard:guard + be.rows] = Vp[t * be.rows:(t + 1) * be.rows]
+        be.grads_window(t, box[guard:guard + be.rows], out)
+        assert torch.isfinite(out).all()
+    assert torch.isfinite(be.part[:m]).all()
+
+
+@pytest.mark.parametrize('loss,q', [('mse', 1), ('wmrb', 1), ('wmrb', 2)])
+def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
+    """Two ranks on cuda:0 (gloo group, host-staged collectives - tools/dp_rehearsal.py with q windows per rank): each owns
+    half of the padded catalog, receives the other half window by window, and the per-window reduce hands every owner the
+    summed gradient of its rows.  Against the single-process resident fit: same loss trajectory, tables equal except
+    where a gradient element is ~0 (different summation order)."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / 'shard.json'
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'dp_rehearsal.py'), str(out), loss, str(q)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+    res = json.loads(out.read_text())
+    (b0, e0), (b1, e1) = res['blocks']
+    assert b0 == 0 and e0 == b1 and e1 == 3001 and 0 < e0 < 3001
+    (i0, i1), (j0, j1) = res['item_blocks']
+    assert i0 == 0 and i1 == j0 and j1 == 701 and 0 < i1 < 701          # the catalog is split, nobody owns all of it
+    assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-6 * abs(res['loss_one'][0])
+    assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
+    assert res['U1_frac_close'] > 0.99 and res['U1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
+    assert res['V1_frac_close'] > 0.99 and res['V1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6

@@ -3,7 +3,10 @@ group (RCCL refuses duplicate devices), so dist.py stages the collectives throug
 passes run on the HIP engine - the same code path bench.py --gpus N takes, minus the wire.
 Rank 0 also runs the single-process fit and writes the comparison as JSON.
 
-env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT;  usage: python tools/dp_rehearsal.py OUT.json [loss]"""
+With a third argument q >= 1 the ranks run the item-row-sharded fit instead (model.shard_items = q windows per rank:
+dist.ItemShardedEpoch - window broadcasts, per-window reduce into the owner), compared with the same single-process fit.
+
+env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT;  usage: python tools/dp_rehearsal.py OUT.json [loss] [q]"""
 import json
 import os
 import sys
@@ -22,6 +25,7 @@ from teamoflow_amd import dist as tdist  # noqa: E402
 
 def main():
     out, loss = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'wmrb')
+    shard = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo', rank=rank, world_size=world)
     rng = np.random.default_rng(7)
@@ -43,10 +47,13 @@ def main():
         else:
             kw.update(loss_graph=MSELoss())
         model = MatrixFactorization(r, **kw)
-        model.verbose, model.data_parallel = False, parallel
+        model.verbose, model.data_parallel = False, parallel and not shard
+        model.shard_items = shard if parallel else 0
         if loss == 'wmrb':
             model.random_ind = torch.as_tensor(R)
         model.fit(epochs, eye(m), eye(n), SparseInteractions(idx, val, (m, n)), lr=lr)
+        if parallel and shard:   # the catalog fits here: assemble it for the comparison
+            model.item_embedding = tdist.gather_item_embedding(model, n)
         return model
 
     dp1 = run(True, 1)                                         # one epoch: U must not depend on the partition at all
@@ -55,9 +62,14 @@ def main():
     U_dp = tdist.gather_user_embedding(dp, m)
     blocks = [None] * world
     dist.all_gather_object(blocks, dp.user_block)
+    item_blocks = [None] * world
+    dist.all_gather_object(item_blocks, getattr(dp, 'item_block', None))
     if rank == 0:
         one, one1 = run(False), run(False, 1)
         res = {'U1_equal': bool(torch.equal(U_dp1, one1.user_embedding)),
+               'U1_frac_close': float(((U_dp1 - one1.user_embedding).abs() <= 1e-6).float().mean()),
+               'U1_max_abs_diff': float((U_dp1 - one1.user_embedding).abs().max()),
+               'item_blocks': item_blocks, 'shard_items': shard,
                'V1_frac_close': float(((dp1.item_embedding - one1.item_embedding).abs() <= 1e-6).float().mean()),
                'V1_max_abs_diff': float((dp1.item_embedding - one1.item_embedding).abs().max()),
                'world': world, 'loss': loss, 'blocks': blocks,
