@@ -348,8 +348,7 @@ class Workload:
             bounds = tdist.partition_users(_engine._excl_cumsum(deg), world, per_user_cost=S if loss == 'wmrb' else 0)
             b, e = bounds[rank], bounds[rank + 1]
             keep = (idx[:, 0] >= b) & (idx[:, 0] < e)
-            idx, val = idx[keep].clone(), val[keep].clone()
-            idx[:, 0] -= b
+            idx, val = _engine.take_interactions(idx, val, keep, user_offset=b)
             U0 = init_table(m, r, 11, dev)[b:e].clone()
             self.user_block, m = (b, e), e - b
         else:
@@ -440,9 +439,10 @@ def hbm_leg(args, dev, name, m, n, nnz, r, S, loss, dtype, steps, warmup):
     return out
 
 
-def api_fit(dev, wl, args, epochs):
+def api_fit(dev, wl, args, epochs, shard_items=0):
     """The same workload through the PUBLIC class surface: MatrixFactorization(...).fit(epochs) - plan build and epoch loop
-    timed by the model itself (plan_seconds_, fit_seconds_)."""
+    timed by the model itself (plan_seconds_, fit_seconds_).  shard_items = q > 0: the item-row-sharded form (one rank
+    streaming its own V in q windows, two staged at a time - what every rank of a sharded job runs, minus the wire)."""
     from teamoflow_amd.mf.initializer_graphs import FixedInitializer
     from teamoflow_amd.mf.loss_graphs import MSELoss, WMRBLoss
     from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
@@ -453,7 +453,7 @@ def api_fit(dev, wl, args, epochs):
     else:
         kw.update(loss_graph=MSELoss())
     model = MatrixFactorization(wl.r, **kw)
-    model.verbose = False
+    model.verbose, model.shard_items = False, shard_items
     if wl.loss == 'wmrb':
         model.random_ind = wl.R
     model.fit(epochs, eye(wl.m), eye(wl.n), SparseInteractions(wl.idx, wl.val, (wl.m, wl.n)), lr=args.lr)
@@ -608,6 +608,12 @@ def main():
         out['api_fit'] = api_fit(dev, wl, args, args.steps + args.warmup)
         out['api_fit'].update(engine_ms_per_epoch_same_epochs=engine_ms,
                               api_over_engine=out['api_fit']['ms_per_epoch'] / engine_ms)
+        if default_workload:
+            q = 4
+            out['item_sharded_fit'] = api_fit(dev, wl, args, args.steps + args.warmup, shard_items=q)
+            out['item_sharded_fit'].update(windows=q, over_resident=out['item_sharded_fit']['ms_per_epoch'] / out['api_fit']['ms_per_epoch'],
+                                           note='model.shard_items = 4 on ONE rank: the catalog walked in 4 windows (twice for WMRB), per-window '
+                                                'launches of the same kernels, user-gradient partials summed in window order; no collective runs')
     if rank == 0 and world == 1 and (args.small_configs or not args.no_extras):
         # the reference's own (dense, full-batch) formulation on the host cores next to the engine, BASELINE configs 1-3
         out['reference_formulation_cpu'] = small_configs(dev, quick=not args.small_configs)

@@ -25,6 +25,15 @@ def _excl_cumsum(x):
     return out
 
 
+def take_interactions(indices, values, keep, user_offset=0, item_offset=0):
+    """(indices[keep] - offsets, values[keep]) of a COO list, selected COLUMN BY COLUMN.  Row-indexing a [nnz, 2] int64 device
+    tensor with a mask (or index_select) returns wrong rows beyond ~6e7 rows on this PyTorch-ROCm build
+    (tools/torch_row_index_probe.py: wrong from 7e7 rows on, 1-D masked selects stay correct) - and C4 has 1e8."""
+    u = indices[:, 0][keep] - user_offset
+    j = indices[:, 1][keep] - item_offset
+    return torch.stack([u, j], dim=1), values[keep]
+
+
 def stable_order(keys, n_rows):
     """(perm, rowptr): stable order of int keys in [0, n_rows) and the row pointers of the sorted list.
     Device tensors go through libtmf (tmf_stable_order_i32: rocPRIM radix sort + binary-search row pointers);
@@ -131,8 +140,11 @@ class InteractionPlan:
         u = indices[:, 0].contiguous()
         j = indices[:, 1].contiguous()
         nnz = u.numel()
-        if nnz and (int(u.min()) < 0 or int(u.max()) >= n_users or int(j.min()) < 0 or int(j.max()) >= n_items):
-            raise IndexError('interaction indices outside dense_shape')
+        if nnz:
+            lo_u, hi_u, lo_j, hi_j = int(u.min()), int(u.max()), int(j.min()), int(j.max())
+            if lo_u < 0 or hi_u >= n_users or lo_j < 0 or hi_j >= n_items:
+                raise IndexError(f'interaction indices outside dense_shape: users [{lo_u}, {hi_u}] of {n_users}, '
+                                 f'items [{lo_j}, {hi_j}] of {n_items}')
         values = values.to(torch.float32).contiguous()
         self.nnz, self.n_users, self.n_items = nnz, n_users, n_items
         if indices.is_cuda and nnz < 2 ** 31:
@@ -359,9 +371,12 @@ class WmrbPlan:
 
 
 class TrainState:
-    """Double-buffered factor tables [rows, ld] and the scratch the passes need."""
+    """Double-buffered factor tables [rows, ld] and the scratch the passes need.
+    ``V_tables`` = (V, V_nxt) already padded: several states (the user batches of a mini-batch fit) step the SAME item table;
+    ``scratch`` = a dict shared by such states: the per-step buffers are allocated once at the largest size any of them needs
+    (``share_scratch``) instead of once per state."""
 
-    def __init__(self, U0, V0, plan, n_components, wplan=None, dtype=torch.float32):
+    def __init__(self, U0, V0, plan, n_components, wplan=None, dtype=torch.float32, V_tables=None, scratch=None):
         dev = plan.col_u.device
         self.r = int(n_components)
         if dtype not in (torch.float32, torch.bfloat16):
@@ -370,21 +385,37 @@ class TrainState:
         self.sfx = '_bf16' if dtype is torch.bfloat16 else '_f32'
         self.ld = _lib.padded_ld(self.r, dtype)
         self.U = self._pad(U0, dev)
-        self.V = self._pad(V0, dev)
         self.U_nxt = torch.empty_like(self.U)
-        self.V_nxt = torch.empty_like(self.V)
+        if V_tables is None:
+            self.V = self._pad(V0, dev)
+            self.V_nxt = torch.empty_like(self.V)
+        else:
+            self.V, self.V_nxt = V_tables
         self.plan, self.wplan = plan, wplan
-        n_slab = max(plan.seg_u.n_slab, plan.seg_i.n_slab if plan.seg_i else 0, wplan.seg_e.n_slab if wplan else 0, 1)
-        self.slab = torch.empty(n_slab, self.ld, dtype=torch.float32, device=dev)
-        n_part = max(plan.seg_u.nseg, plan.n_users, 1)
-        self.loss_part = torch.zeros(n_part, dtype=torch.float32, device=dev)
+        need = dict(slab=max(plan.seg_u.n_slab, plan.seg_i.n_slab if plan.seg_i else 0, wplan.seg_e.n_slab if wplan else 0, 1) * self.ld,
+                    loss_part=max(plan.seg_u.nseg, plan.n_users, 1))
         if wplan is not None and wplan.sliced:
             m, S = wplan.R.shape
-            self.sp = torch.empty(m, S, dtype=torch.float32, device=dev)      # sampled scores, R-sorted order
-            self.pk = torch.empty(max(plan.nnz, 1), dtype=torch.float32, device=dev)  # scores of the interactions, CSR order
             # gradU partials: one layer per slice, or (above PART_BUDGET bytes) a single layer summed by per-slice launches
             self.part_layers = wplan.n_slices if wplan.n_slices * m * self.ld * 4 <= PART_BUDGET else 1
-            self.part = torch.empty(self.part_layers * max(m, 1), self.ld, dtype=torch.float32, device=dev)
+            need.update(sp=m * S, pk=max(plan.nnz, 1), part=self.part_layers * max(m, 1) * self.ld)
+        self._need = need
+        if scratch is None:
+            self._bind({k: torch.zeros(v, dtype=torch.float32, device=dev) if k == 'loss_part'
+                        else torch.empty(v, dtype=torch.float32, device=dev) for k, v in need.items()})
+        else:
+            scratch.setdefault('states', []).append(self)
+
+    def _bind(self, bufs):
+        """Views of the (possibly shared, larger) flat fp32 scratch buffers in this state's shapes."""
+        need = self._need
+        self.slab = bufs['slab'][:need['slab']].view(-1, self.ld)
+        self.loss_part = bufs['loss_part'][:need['loss_part']]
+        if 'sp' in need:
+            m, S = self.wplan.R.shape
+            self.sp = bufs['sp'][:need['sp']].view(m, S)               # sampled scores, R-sorted order
+            self.pk = bufs['pk'][:need['pk']]                          # scores of the interactions, CSR order
+            self.part = bufs['part'][:need['part']].view(-1, self.ld)
 
     def _pad(self, W, dev):
         W = torch.as_tensor(W).detach().to(device=dev, dtype=torch.float32)
@@ -395,6 +426,19 @@ class TrainState:
     def swap(self):
         self.U, self.U_nxt = self.U_nxt, self.U
         self.V, self.V_nxt = self.V_nxt, self.V
+
+
+def share_scratch(scratch, dev):
+    """Allocate the per-step buffers of the states registered in ``scratch`` once, at the largest size any of them needs."""
+    states = scratch.get('states', [])
+    sizes = {}
+    for st in states:
+        for k, v in st._need.items():
+            sizes[k] = max(sizes.get(k, 0), v)
+    bufs = {k: torch.zeros(v, dtype=torch.float32, device=dev) for k, v in sizes.items()}
+    for st in states:
+        st._bind(bufs)
+    return bufs
 
 
 class KernelTimer:

@@ -82,9 +82,8 @@ class WindowedHipBackend:
             self.sub = []
             for t in range(self.T):
                 keep = (item >= t * self.rows) & (item < (t + 1) * self.rows)
-                idx_t = indices[keep].clone()
-                idx_t[:, 1] -= t * self.rows
-                self.sub.append(_engine.InteractionPlan(idx_t, values[keep], m, self.rows, csc=True))
+                idx_t, val_t = _engine.take_interactions(indices, values, keep, item_offset=t * self.rows)
+                self.sub.append(_engine.InteractionPlan(idx_t, val_t, m, self.rows, csc=True))
             n_slab = max([max(p.seg_u.n_slab, p.seg_i.n_slab) for p in self.sub] + [1])
             self.loss_part = torch.zeros(max([p.seg_u.nseg for p in self.sub] + [1]), dtype=torch.float32, device=dev)
             self.loss_w = torch.zeros(self.T, dtype=torch.float64, device=dev)

@@ -302,8 +302,10 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     - ``model.local_items = True`` - only the initial rows of the items it owns).  On return ``user_embedding`` is this
     rank's user block, ``item_embedding`` its item rows, ``user_block`` / ``item_block`` their global ranges;
     ``gather_item_embedding`` assembles the catalog where it fits."""
+    import timeit
     from ._windowed import WindowedHipBackend, pad_table, window_geometry
     from .mf.loss_graphs import WMRBLoss
+    t_plan = timeit.default_timer()
     world, rank = _world(group)
     dev = interactions.device
     wmrb = isinstance(model.loss_graph, WMRBLoss)
@@ -322,9 +324,7 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
         bounds = partition_users(rowptr, world, per_user_cost=S)
         b, e = bounds[rank], bounds[rank + 1]
         keep = (u >= b) & (u < e)
-        idx = interactions.indices[keep].clone()
-        idx[:, 0] -= b
-        val = interactions.values[keep]
+        idx, val = _engine.take_interactions(interactions.indices, interactions.values, keep, user_offset=b)
     R, c = None, 0.0
     if wmrb:
         Rall = torch.as_tensor(model.random_ind)
@@ -349,9 +349,13 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     backend = WindowedHipBackend(U_blk, V_own, idx, val, R, e - b, n_items, world * q, r, 'wmrb' if wmrb else 'mse', c, lr, dtype=dtype)
     ep = ItemShardedEpoch(backend, backend.n_loss, windows_per_rank=q, group=group)
     losses = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = timeit.default_timer()
+    model.plan_seconds_ = t0 - t_plan
     for epoch in range(epochs):
         losses[epoch] = ep.step()
     torch.cuda.synchronize(dev)
+    model.fit_seconds_ = timeit.default_timer() - t0
     model.loss_history_ = losses[:epochs].cpu().tolist()
     model._state, model.user_block, model.item_block = backend, (b, e), (min(i0, n_items), min(i1, n_items))
     model.user_embedding = backend.U[:, :r]
@@ -397,9 +401,7 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
         bounds = partition_users(rowptr, world, per_user_cost=S)
         b, e = bounds[rank], bounds[rank + 1]
         keep = (u >= b) & (u < e)
-        idx = interactions.indices[keep].clone()
-        idx[:, 0] -= b
-        val = interactions.values[keep]
+        idx, val = _engine.take_interactions(interactions.indices, interactions.values, keep, user_offset=b)
     n_pad = padded_rows(n_items, world)
     plan = _engine.InteractionPlan(idx, val, e - b, n_pad, user_chunks=1 if wmrb else _engine.mse_user_chunks(), csc=not wmrb)
     ld = _lib.padded_ld(model.n_components, model.factor_dtype)

@@ -94,6 +94,9 @@ class MatrixFactorization:
         # extension: q >= 1 = item-row-sharded V in q windows per rank (dist.fit_item_sharded): the item table is owned in
         # row blocks and streamed window by window instead of being replicated - for catalogs beyond one GPU's memory
         self.shard_items = 0
+        # extension, OFF by default (the reference is full-batch): B > 0 = one optimiser step per batch of B users
+        # (teamoflow_amd/_minibatch.py)
+        self.batch_users = 0
         # extension, OFF by default: 'adam' keeps Adam's moments across epochs.  The reference (and the default here,
         # 'fresh_adam') builds a new optimizer every epoch (:176), i.e. every step is Adam's first step.
         self.optimizer = 'fresh_adam'
@@ -139,10 +142,15 @@ class MatrixFactorization:
         wmrb = isinstance(self.loss_graph, WMRBLoss)
         if wmrb and self.random_ind is None:
             raise SampleTableMissing('WMRBLoss needs generate_sample=True (random_ind is None)')
+        if getattr(self, 'batch_users', 0):
+            if getattr(self, 'shard_items', 0) or self.data_parallel:
+                raise ValueError('batch_users cannot be combined with shard_items / data_parallel')
+            from .. import _minibatch
+            _minibatch.fit_minibatch(self, epochs, n_users, n_items, interactions, lr, U0, V0, self.batch_users)
+            return
         if getattr(self, 'shard_items', 0):
             from .. import dist as tdist
             tdist.fit_item_sharded(self, epochs, n_users, n_items, interactions, lr, U0, V0, windows_per_rank=int(self.shard_items))
-            self.plan_seconds_ = 0.0
             return
         if self.data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size() > 1 or (self.data_parallel == 'force'):

@@ -165,3 +165,62 @@ def test_opt_in_persistent_adam(ns, loss, monkeypatch):
         assert rel_err(got.user_embedding.cpu().numpy(), U) < 2e-2 and rel_err(got.item_embedding.cpu().numpy(), V) < 2e-2
     with pytest.raises(ValueError):
         model('sgd', 1)
+
+
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+def test_minibatch_over_user_batches(loss):
+    """Opt-in extension (model.batch_users): an epoch = one fresh-Adam step per batch of users on that batch's part of the
+    loss, the next batch seeing the updated item table.  Oracle: the same sequence composed from the full-batch closed-form
+    epoch applied to each batch's sub-problem.  batch_users >= n_users is the reference's full-batch fit, bit for bit."""
+    import numpy as np
+    from oracle import sparse_ref as S
+    from teamoflow_amd.mf.initializer_graphs import FixedInitializer
+    from teamoflow_amd.mf.loss_graphs import WMRBLoss
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    from teamoflow_amd.mf.sparse import SparseInteractions, eye
+    rng = np.random.default_rng(3)
+    m, n, r, Sn, lr, B = 103, 57, 12, 9, 0.02, 40          # batches of 40, 40, 23 users
+    A = (rng.random((m, n)) < 0.15) * rng.integers(1, 6, (m, n))
+    idx = np.argwhere(A != 0)
+    val = A[A != 0].astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.choice(n, Sn, replace=False) for _ in range(m)])
+
+    def fit(batch, epochs):
+        kw = dict(user_weight_graph=FixedInitializer(U0), item_weight_graph=FixedInitializer(V0))
+        if loss == 'wmrb':
+            kw.update(loss_graph=WMRBLoss(), n_users=m, n_items=n, n_samples=Sn)
+        model = MatrixFactorization(r, **kw)
+        model.verbose, model.batch_users = False, batch
+        if loss == 'wmrb':
+            model.random_ind = torch.as_tensor(R)
+        model.fit(epochs, eye(m), eye(n), SparseInteractions(idx, val, (m, n)), lr=lr)
+        return model
+
+    model = fit(B, 2)
+    U, V = U0.copy(), V0.copy()
+    ref = []
+    for _ in range(2):
+        tot, cnt = 0.0, 0
+        for b0 in range(0, m, B):
+            b1 = min(b0 + B, m)
+            keep = (idx[:, 0] >= b0) & (idx[:, 0] < b1)
+            sub = idx[keep].copy()
+            sub[:, 0] -= b0
+            if loss == 'mse':
+                U[b0:b1], V, _, t = S.mse_epoch(U[b0:b1], V, sub, val[keep], lr)
+                cnt += int(keep.sum())
+            else:
+                U[b0:b1], V, _, t = S.wmrb_epoch(U[b0:b1], V, sub, val[keep], R[b0:b1], n, Sn, lr)
+                cnt += int((val[keep] > 0).sum())
+            tot += float(t['loss'].astype(np.float64).sum())
+        ref.append(tot / cnt)
+    assert np.allclose(model.loss_history_, ref, rtol=2e-5), (model.loss_history_, ref)
+    dU = np.abs(model.user_embedding.cpu().numpy() - U)
+    dV = np.abs(model.item_embedding.cpu().numpy() - V)
+    assert (dU < 1e-4).mean() > 0.98 and dU.max() <= 2 * 2 * lr            # near-sign steps: elements with g ~ 0 may differ by a step
+    assert (dV < 1e-4).mean() > 0.95 and dV.max() <= 2 * 6 * lr
+    full, one = fit(0, 2), fit(m + 5, 2)
+    assert one.loss_history_ == full.loss_history_ and torch.equal(one.item_embedding, full.item_embedding)
+    assert torch.equal(one.user_embedding, full.user_embedding)

@@ -184,3 +184,21 @@ def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
     assert res['U1_frac_close'] > 0.99 and res['U1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
     assert res['V1_frac_close'] > 0.99 and res['V1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
+
+
+def test_user_block_selection_at_full_size():
+    """Cutting a COO list of C4 size into user blocks: _engine.take_interactions selects column by column because row-indexing a
+    [nnz, 2] int64 tensor by a mask returns wrong rows beyond ~6e7 rows on this PyTorch-ROCm build
+    (tools/torch_row_index_probe.py).  Checked against arithmetic the selection must reproduce."""
+    from teamoflow_amd import _engine
+    dev = torch.device('cuda')
+    n = 100_000_000
+    k = torch.arange(n, device=dev)
+    idx = torch.stack([k // 100, k % 100000], 1)
+    val = (k % 5 + 1).float()
+    b, e = 300_000, 950_000
+    keep = (idx[:, 0] >= b) & (idx[:, 0] < e)
+    sub, v = _engine.take_interactions(idx, val, keep, user_offset=b)
+    kk = torch.arange(b * 100, e * 100, device=dev)
+    assert sub.shape == (kk.numel(), 2) and torch.equal(sub[:, 0], kk // 100 - b) and torch.equal(sub[:, 1], kk % 100000)
+    assert torch.equal(v, (kk % 5 + 1).float())
