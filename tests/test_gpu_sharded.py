@@ -202,3 +202,37 @@ def test_user_block_selection_at_full_size():
     kk = torch.arange(b * 100, e * 100, device=dev)
     assert sub.shape == (kk.numel(), 2) and torch.equal(sub[:, 0], kk // 100 - b) and torch.equal(sub[:, 1], kk % 100000)
     assert torch.equal(v, (kk % 5 + 1).float())
+
+
+@pytest.mark.parametrize('loss', ['wmrb', 'mse'])
+def test_windowed_fit_at_c4_size_follows_the_resident_fit(tm, loss):
+    """BASELINE config 4 (1M x 100K, r=128, S=1024, 1e8 interactions) with the catalog in 4 windows of 4 slices: two epochs
+    through the public API against the resident fit from the same start.  Epoch 1 evaluates the same tables, so the loss agrees
+    to fp32 summation order; the tables differ only where a gradient element is ~0 (window-ordered sums)."""
+    import bench
+    from teamoflow_amd.mf.utils import random_sampler_device
+    dev = torch.device('cuda')
+    m, n, r, Sn, lr = 1_000_000, 100_000, 128, 1024, 0.1
+    idx, val = bench.gen_interactions(m, n, 100_000_000, 'zipf', 0, dev)
+    U0, V0 = bench.init_table(m, r, 11, dev), bench.init_table(n, r, 7, dev)
+    R = random_sampler_device(n, m, Sn, seed=100, device=dev) if loss == 'wmrb' else None
+
+    def run(shard):
+        kw = dict(user_weight_graph=tm.Fixed(U0), item_weight_graph=tm.Fixed(V0))
+        if loss == 'wmrb':
+            kw.update(loss_graph=tm.WMRB(), n_users=m, n_items=n, n_samples=Sn)
+        model = tm.MF(r, **kw)
+        model.verbose, model.shard_items, model.random_ind = False, shard, R
+        model.fit(2, tm.eye(m), tm.eye(n), tm.Sparse(idx, val, (m, n)), lr=lr)
+        out = (model.loss_history_, model.user_embedding.clone(), model.item_embedding.clone(),
+               (model._state.T, model._state.k) if shard else None)
+        del model
+        torch.cuda.empty_cache()
+        return out
+    la, Ua, Va, geom = run(4)
+    lb, Ub, Vb, _ = run(0)
+    assert geom == (4, 4)
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]) and abs(la[1] - lb[1]) <= 1e-4 * abs(lb[1])
+    for a, b in ((Ua, Ub), (Va, Vb)):
+        d = (a - b).abs()
+        assert float((d <= 1e-5).float().mean()) > 0.99 and float(d.max()) <= 2 * 2 * lr + 1e-6
