@@ -358,9 +358,41 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     model.fit_seconds_ = timeit.default_timer() - t0
     model.loss_history_ = losses[:epochs].cpu().tolist()
     model._state, model.user_block, model.item_block = backend, (b, e), (min(i0, n_items), min(i1, n_items))
+    model._sharded_epoch, model._n_items_fit = ep, n_items
     model.user_embedding = backend.U[:, :r]
     model.item_embedding = V_own[:max(0, min(i1, n_items) - i0), :r]
     model.user_trainable, model.item_trainable = [model.user_embedding], [model.item_embedding]
+
+
+def sharded_top_items(model, k, clamp_negatives=False, users=None):
+    """Top-k item ids (int32, global) of THIS rank's users over the whole item-row-sharded catalog - what ``recall_at_k`` /
+    ``retrieve_user_recs`` (matrix_factorization.py:236-248, :424-438) rank with.  A collective: every rank calls it (with its own
+    users); the windows are broadcast once more and each is ranked by the fused GEMM + top-k kernel, the per-window lists
+    (value desc, index asc - already in catalog order among equal values, because windows are visited in item order) are merged
+    by one more stable top-k over the <= T k candidates.  Scores are the same MFMA dot products as on the resident path, so the
+    result is identical to ranking the assembled table."""
+    from . import _ops
+    ep, be = model._sharded_epoch, model._state
+    r, n_items = model.n_components, model._n_items_fit
+    U = be.U[:, :r] if users is None else be.U[users:users + 1, :r]
+    vals, ids = [], []
+    for t, Vwin in ep._windows():
+        valid = min(be.rows, n_items - t * be.rows)        # rows beyond the catalog are padding: never candidates
+        if valid <= 0 or U.shape[0] == 0:
+            continue
+        kt = min(int(k), valid)
+        W = Vwin[:valid, :r]
+        if _ops.fused_topk_supported(U, W, kt):
+            v, i = _ops.predict_topk(U, W, kt, clamp_negatives=clamp_negatives, return_values=True)
+        else:
+            v, i = _ops.topk_stable(_ops.predict_gemm(U.float(), W.float()), kt, clamp_negatives=clamp_negatives, return_values=True)
+        vals.append(v)
+        ids.append(i + t * be.rows)
+    if not vals:
+        return torch.zeros(U.shape[0], 0, dtype=torch.int32, device=be.U.device)
+    cv, ci = torch.cat(vals, dim=1), torch.cat(ids, dim=1)
+    pos = _ops.topk_stable(cv, min(int(k), cv.shape[1]), clamp_negatives=clamp_negatives)
+    return torch.gather(ci, 1, pos.to(torch.int64))
 
 
 def gather_item_embedding(model, n_items, group=None):

@@ -135,6 +135,7 @@ class MatrixFactorization:
 
     def _fit_sparse(self, epochs, n_users, n_items, interactions, lr, U0, V0):
         _lib.get()  # fail loudly here when the HIP engine cannot run
+        self._sharded_epoch = None
         dev = default_device()
         t_plan = timeit.default_timer()
         if interactions.device != dev:
@@ -254,6 +255,7 @@ class MatrixFactorization:
         self.item_trainable = [self.item_embedding]
 
     def _fit_generic(self, epochs, user_features, item_features, interactions, lr, U, V):
+        self._sharded_epoch = None
         """The reference's dense loop (:128-187) over arbitrary plug-ins, differentiated by autograd."""
         dev = U.device
         interactions = interactions.to(dev)
@@ -319,6 +321,11 @@ class MatrixFactorization:
     # ------------------------------------------------------------------------------------------
     def predict(self, A=None):
         """:189-201.  All scores [n_users, n_items]; with A also the scores where A == 0 (row-major)."""
+        ep = getattr(self, '_sharded_epoch', None)
+        if ep is not None and ep.world > 1:
+            raise NotImplementedError('item-row-sharded fit: this rank holds only its item rows, the dense [n_users, n_items] score '
+                                      'matrix is not available; recall_at_k / precision_at_k / retrieve_user_recs rank over the '
+                                      'windows (dist.sharded_top_items), dist.gather_item_embedding assembles the table where it fits')
         all_predictions = _ops.predict_gemm(self.user_embedding, self.item_embedding)
         if A is not None:
             A = torch.as_tensor(A).to(all_predictions.device)
@@ -338,6 +345,12 @@ class MatrixFactorization:
     def _top_items(self, k, clamp, users=None):
         """Top-k item ids (int32) for every user, scored block by block: the [m, n] matrix is only
         ever materialised one block of users at a time."""
+        ep = getattr(self, '_sharded_epoch', None)
+        if ep is not None and ep.world > 1:
+            # item-row-sharded fit: item_embedding holds only this rank's rows - rank over the windows (a collective)
+            from .. import dist as tdist
+            top = tdist.sharded_top_items(self, k, clamp, users=users)
+            return top[0] if users is not None else top
         if users is not None:
             scores = _ops.predict_gemm(self.user_embedding[users:users + 1], self.item_embedding)
             return _ops.topk_stable(scores, k, clamp_negatives=clamp)[0]
@@ -358,12 +371,14 @@ class MatrixFactorization:
             A = A.to(top.device)
             m, n = A.dense_shape
             nz = A.values != 0
-            keys = torch.sort(A.indices[nz, 0] * n + A.indices[nz, 1])[0]
+            # column first, mask second: masked ROW selection of a [nnz, 2] tensor is unreliable beyond ~6e7 rows on this
+            # PyTorch-ROCm build (tools/torch_row_index_probe.py)
+            keys = torch.sort(A.indices[:, 0][nz] * n + A.indices[:, 1][nz])[0]
             q = torch.arange(m, device=top.device)[:, None] * n + top.to(torch.int64)
             pos = torch.clamp(torch.searchsorted(keys, q.reshape(-1)), max=max(keys.numel() - 1, 0))
             found = (keys[pos] == q.reshape(-1)).reshape(q.shape) if keys.numel() else torch.zeros_like(q, dtype=torch.bool)
             hits = found.sum(dim=1).to(torch.float32)
-            relevant = torch.bincount(A.indices[A.values > 0, 0], minlength=m).to(torch.float32)
+            relevant = torch.bincount(A.indices[:, 0][A.values > 0], minlength=m).to(torch.float32)
             return hits, relevant
         A = torch.as_tensor(A).to(device=top.device, dtype=torch.float32)
         res_top_k = gather_matrix_indices(A, top.to(torch.int64))

@@ -182,6 +182,7 @@ def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
     assert i0 == 0 and i1 == j0 and j1 == 701 and 0 < i1 < 701          # the catalog is split, nobody owns all of it
     assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-6 * abs(res['loss_one'][0])
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
+    assert res["sharded_top10_equals_resident"] is True
     assert res['U1_frac_close'] > 0.99 and res['U1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
     assert res['V1_frac_close'] > 0.99 and res['V1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
 
@@ -236,3 +237,27 @@ def test_windowed_fit_at_c4_size_follows_the_resident_fit(tm, loss):
     for a, b in ((Ua, Ub), (Va, Vb)):
         d = (a - b).abs()
         assert float((d <= 1e-5).float().mean()) > 0.99 and float(d.max()) <= 2 * 2 * lr + 1e-6
+
+
+@pytest.mark.parametrize('k,r,dtype', [(10, 24, torch.float32), (64, 24, torch.float32), (100, 24, torch.float32), (10, 32, torch.bfloat16)])
+def test_ranking_over_windows_equals_ranking_the_table(tm, k, r, dtype):
+    """recall_at_k / retrieve_user_recs on an item-row-sharded model rank window by window and merge the per-window lists
+    (dist.sharded_top_items).  On one rank the table is also available whole: both rankings must be identical, including the
+    order among tied scores (clamped negatives tie at 0 across windows) and with windows narrower than k."""
+    from teamoflow_amd import _ops
+    from teamoflow_amd import dist as tdist
+    m, n, Sn = 211, 389, 16
+    idx, val, U0, V0, R = problem(9, m, n, r, Sn)
+    V0[5::11] = V0[4::11][:len(V0[5::11])]                    # duplicate item rows: exact score ties across and inside windows
+    model = fit(tm, U0, V0, idx, val, (m, n), 1, 0.0, 'wmrb', R, Sn, 6, dtype=dtype)     # lr = 0: the tables stay as given
+    assert model._state.rows < 100                           # narrower than k = 100
+    for clamp in (False, True):
+        got = tdist.sharded_top_items(model, k, clamp)
+        Ue, Ve = model.user_embedding, model.item_embedding
+        if _ops.fused_topk_supported(Ue, Ve, k):
+            want = _ops.predict_topk(Ue, Ve, k, clamp_negatives=clamp)
+        else:
+            want = _ops.topk_stable(_ops.predict_gemm(Ue.float(), Ve.float()), k, clamp_negatives=clamp)
+        assert torch.equal(got, want)
+        one = tdist.sharded_top_items(model, k, clamp, users=17)
+        assert torch.equal(one[0], want[17])

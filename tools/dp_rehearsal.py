@@ -53,6 +53,7 @@ def main():
             model.random_ind = torch.as_tensor(R)
         model.fit(epochs, eye(m), eye(n), SparseInteractions(idx, val, (m, n)), lr=lr)
         if parallel and shard:   # the catalog fits here: assemble it for the comparison
+            model.top10_sharded = model._top_items(10, True)     # ranked over the windows (a collective), before the table is assembled
             model.item_embedding = tdist.gather_item_embedding(model, n)
         return model
 
@@ -60,6 +61,14 @@ def main():
     U_dp1 = tdist.gather_user_embedding(dp1, m)
     dp = run(True)
     U_dp = tdist.gather_user_embedding(dp, m)
+    topk_equal = None
+    if shard:
+        # ranking over the sharded catalog == ranking the assembled tables with the resident fused kernel, exactly
+        from teamoflow_amd import _ops
+        mine = _ops.predict_topk(dp.user_embedding, dp.item_embedding, 10, clamp_negatives=True)
+        same = [None] * world
+        dist.all_gather_object(same, bool(torch.equal(mine, dp.top10_sharded)))
+        topk_equal = all(same)
     blocks = [None] * world
     dist.all_gather_object(blocks, dp.user_block)
     item_blocks = [None] * world
@@ -69,7 +78,7 @@ def main():
         res = {'U1_equal': bool(torch.equal(U_dp1, one1.user_embedding)),
                'U1_frac_close': float(((U_dp1 - one1.user_embedding).abs() <= 1e-6).float().mean()),
                'U1_max_abs_diff': float((U_dp1 - one1.user_embedding).abs().max()),
-               'item_blocks': item_blocks, 'shard_items': shard,
+               'item_blocks': item_blocks, 'shard_items': shard, 'sharded_top10_equals_resident': topk_equal,
                'V1_frac_close': float(((dp1.item_embedding - one1.item_embedding).abs() <= 1e-6).float().mean()),
                'V1_max_abs_diff': float((dp1.item_embedding - one1.item_embedding).abs().max()),
                'world': world, 'loss': loss, 'blocks': blocks,
