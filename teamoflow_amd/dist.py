@@ -345,6 +345,8 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     elif i0 < n_items:
         V_own[:min(i1, n_items) - i0] = pad_table(V0[i0:min(i1, n_items)], ld, dtype, dev, r)
     U_blk = torch.as_tensor(U0).detach()
+    if local is not None and U_blk.shape[0] != e - b:
+        raise ValueError(f'local_users = {local}: the user initialiser must return the {e - b} rows of this block')
     U_blk = U_blk if local is not None else U_blk[b:e]
     backend = WindowedHipBackend(U_blk, V_own, idx, val, R, e - b, n_items, world * q, r, 'wmrb' if wmrb else 'mse', c, lr, dtype=dtype)
     ep = ItemShardedEpoch(backend, backend.n_loss, windows_per_rank=q, group=group)
