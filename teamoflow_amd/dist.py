@@ -306,6 +306,8 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     from ._windowed import WindowedHipBackend, pad_table, window_geometry
     from .mf.loss_graphs import WMRBLoss
     t_plan = timeit.default_timer()
+    if getattr(model, 'optimizer', 'fresh_adam') != 'fresh_adam':
+        raise ValueError("the multi-GPU fits implement the reference's optimiser only (optimizer='fresh_adam')")
     world, rank = _world(group)
     dev = interactions.device
     wmrb = isinstance(model.loss_graph, WMRBLoss)
@@ -419,6 +421,8 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
     On return the model holds ``item_embedding`` (replicated), ``user_embedding`` = this rank's block,
     ``user_block`` = (begin, end); ``gather_user_embedding(model)`` assembles the full table."""
     from .mf.loss_graphs import WMRBLoss
+    if getattr(model, 'optimizer', 'fresh_adam') != 'fresh_adam':
+        raise ValueError("the multi-GPU fits implement the reference's optimiser only (optimizer='fresh_adam')")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = interactions.device
     wmrb = isinstance(model.loss_graph, WMRBLoss)

@@ -468,6 +468,11 @@ class MatrixFactorization:
         plug-ins are stored as plain data (class name + constructor state), so the file loads with
         ``torch.load(weights_only=True)``; a user-defined plug-in object can only be stored pickled
         (``allow_pickle=True`` here AND in ``load``).  ``include_samples=False`` leaves the [m, S] negative table out."""
+        ep = getattr(self, '_sharded_epoch', None)
+        if ep is not None and ep.world > 1:
+            raise ValueError('item-row-sharded model: this rank holds users %s and item rows %s only - assemble the tables first '
+                             '(dist.gather_user_embedding / gather_item_embedding) or save one file per rank from them'
+                             % (self.user_block, self.item_block))
         _save_to_disk(self, path, include_samples, allow_pickle)
 
     @classmethod
