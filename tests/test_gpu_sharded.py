@@ -261,3 +261,32 @@ def test_ranking_over_windows_equals_ranking_the_table(tm, k, r, dtype):
         assert torch.equal(got, want)
         one = tdist.sharded_top_items(model, k, clamp, users=17)
         assert torch.equal(one[0], want[17])
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('TMF_FUZZ_SEEDS', '12'))))   # TMF_FUZZ_SEEDS=300 for a soak run
+def test_randomized_windowed_shapes_against_oracle(tm, monkeypatch, seed):
+    """Random problem shapes, window counts and slice sizes (windows wider or narrower than the catalog, empty windows, users
+    without interactions, ranks across the lane geometries): one windowed epoch against the fp64 closed form."""
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(1000 + seed)
+    m, n = int(rng.integers(1, 260)), int(rng.integers(2, 400))
+    r = int(rng.choice([1, 3, 8, 17, 32, 64, 100, 128, 200, 256]))
+    Sn = int(rng.integers(1, max(2, min(n, 40))))
+    T = int(rng.integers(1, 9))
+    loss = 'wmrb' if seed % 2 else 'mse'
+    monkeypatch.setattr(tm.windowed, 'WINDOW_SLICE_BYTES', int(rng.choice([512, 4096, 1 << 22])))
+    idx, val, U0, V0, R = problem(2000 + seed, m, n, r, Sn, density=float(rng.choice([0.02, 0.1, 0.3])))
+    lr = 0.05
+    model = fit(tm, U0, V0, idx, val, (m, n), 1, lr, loss, R, Sn, T)
+    U64, V64 = U0.astype(np.float64), V0.astype(np.float64)
+    sU = sV = None
+    if loss == 'mse':
+        _, _, mean, t = S.mse_epoch(U64, V64, idx, val.astype(np.float64), lr)
+    else:
+        _, _, mean, t = S.wmrb_epoch(U64, V64, idx, val.astype(np.float64), R, n, Sn, lr)
+        sl = S.wmrb_slack(U64, V64, idx, val.astype(np.float64), R, n, Sn)
+        sU, sV = sl['gU'], sl['gV']
+    if np.isfinite(mean):
+        assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+    assert_step(model.user_embedding.cpu().numpy(), U0, t['gU'], lr, what=f'{loss} U', slack=sU)
+    assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], lr, what=f'{loss} V', slack=sV)
