@@ -21,12 +21,15 @@ from . import _engine, _lib
 WINDOW_SLICE_BYTES = 4 << 20   # V rows per slice inside a window (the resident path's slice size)
 
 
-def window_geometry(n_items, n_windows, ld, elem_size):
-    """(rows per window, slices per window, padded catalog rows): windows hold a whole number of ~4 MB slices and the padded
-    catalog a whole number of windows (rows >= n_items have no interactions and stay zero)."""
+def window_geometry(n_items, n_windows, ld, elem_size, world=1):
+    """(rows per window, slices per window, padded catalog rows): a window holds a whole number of ~4 MB slices and of the
+    ``world`` ownership sub-blocks, the padded catalog a whole number of windows (rows >= n_items have no interactions and
+    stay zero)."""
+    import math
     rows = max(1, -(-n_items // n_windows))
     k = int(min(max(1, -(-rows * ld * elem_size // WINDOW_SLICE_BYTES)), max(1, 256 // n_windows)))
-    rows = -(-rows // k) * k
+    step = k * world // math.gcd(k, world)
+    rows = -(-rows // step) * step
     return rows, k, rows * n_windows
 
 
@@ -38,11 +41,12 @@ def pad_table(W, ld, dtype, dev, r):
 
 
 class WindowedHipBackend:
-    """One rank's users against a windowed catalog.  ``V_own`` are the item rows this rank owns (updated in place by
-    ``adam_rows``); they take part in the passes only through the ``Vwin`` arguments."""
+    """One rank's users against a windowed catalog.  ``V_own`` are the item rows this rank owns (of every window its
+    sub-block, window-major; updated in place by ``adam_rows``); they take part in the passes only through the ``Vwin``
+    arguments.  ``world`` only enters the window geometry (a window must split into that many equal sub-blocks)."""
 
     def __init__(self, U_blk, V_own, indices, values, R, n_users, n_items, n_windows, n_components, loss, c, lr,
-                 dtype=torch.float32, user_chunks=None):
+                 dtype=torch.float32, user_chunks=None, world=1):
         lib = _lib.get()
         dev = indices.device
         self.loss, self.c, self.r, self.T = loss, float(c), int(n_components), int(n_windows)
@@ -51,7 +55,7 @@ class WindowedHipBackend:
         self.sfx = '_bf16' if dtype is torch.bfloat16 else '_f32'
         self.ld = ld = _lib.padded_ld(self.r, dtype)
         esz = 2 if dtype is torch.bfloat16 else 4
-        self.rows, self.k, self.n_pad = window_geometry(n_items, self.T, ld, esz)
+        self.rows, self.k, self.n_pad = window_geometry(n_items, self.T, ld, esz, world)
         self.m = m = int(n_users)
         self.adam = lib.tmf_adam_fresh(float(lr))
         self.U = pad_table(U_blk, ld, dtype, dev, self.r)

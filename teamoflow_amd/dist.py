@@ -192,81 +192,88 @@ def _global_rank(group, r):
     return r if group is None else dist.get_global_rank(group, r)
 
 
-def broadcast_rows(t, owner, group=None):
-    """Broadcast ``t`` from group rank ``owner``; returns a handle whose wait() orders the CURRENT stream after it
-    (RCCL: the collective runs on the communicator's stream, which itself waits for the work already queued on the
-    current stream - so a staging buffer is not overwritten while an earlier kernel still reads it)."""
-    if _world(group)[0] == 1:
+def all_gather_rows_async(out, inp, group=None):
+    """``out`` [world * rows, ld] <- the ranks' ``inp`` [rows, ld] in rank order; returns a handle whose wait() orders the
+    CURRENT stream after it (RCCL: the collective runs on the communicator's stream, which itself first waits for the work
+    already queued on the current stream - so a staging buffer is not overwritten while an earlier kernel still reads it)."""
+    if _staged(group, inp):
+        all_gather_rows(out, inp, group)
         return _Done()
-    if _staged(group, t):
-        h = t.cpu()
-        dist.broadcast(h, _global_rank(group, owner), group=group)
-        t.copy_(h)
-        return _Done()
-    return dist.broadcast(t, _global_rank(group, owner), group=group, async_op=True)
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
 
 
-def reduce_rows_sum(t, owner, group=None):
-    """Sum ``t`` over the ranks into rank ``owner``'s tensor (the content elsewhere is unspecified afterwards)."""
-    if _world(group)[0] == 1:
+def reduce_scatter_sum_async(out, inp, group=None):
+    """``out`` [rows, ld] <- sum over ranks of block `rank` of their ``inp`` [world * rows, ld]."""
+    if _staged(group, inp):
+        reduce_scatter_sum(out, inp, group)
         return _Done()
-    if _staged(group, t):
-        h = t.cpu()
-        dist.reduce(h, _global_rank(group, owner), op=dist.ReduceOp.SUM, group=group)
-        t.copy_(h)
-        return _Done()
-    return dist.reduce(t, _global_rank(group, owner), op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def owned_item_rows(rows_per_window, n_windows, world, rank, device=None):
+    """Global row ids (int64, ascending) of the padded catalog that ``rank`` owns: of every window its ``rank``-th
+    sub-block of rows_per_window / world rows."""
+    sub = rows_per_window // world
+    t = torch.arange(n_windows, device=device, dtype=torch.int64)[:, None] * rows_per_window
+    return (t + rank * sub + torch.arange(sub, device=device, dtype=torch.int64)[None, :]).reshape(-1)
 
 
 class ItemShardedEpoch:
-    """One epoch with item-row-sharded V.  The padded catalog is cut into T = world * windows_per_rank windows of equal row
-    count; rank g owns windows [g q, (g+1) q) - their rows and their optimiser step - and NO rank ever holds more than its
-    own rows plus two staging windows.  Users stay partitioned as in DataParallelEpoch; U is never communicated.
+    """One epoch with item-row-sharded V.  The padded catalog is cut into T windows of equal row count and every window into
+    ``world`` sub-blocks: rank g owns sub-block g of EVERY window - those rows and their optimiser step - so a window is
+    assembled by an all-gather to which every rank contributes 1/world, and its gradient is returned by a reduce-scatter.
+    No rank ever holds more than its own rows (1/world of the table) plus two staging windows.  Users stay partitioned as in
+    DataParallelEpoch; U is never communicated.
 
-        walk 1 (WMRB only)   for every window t, in order:   broadcast(V rows of t from their owner)  ->  scores of t
+        walk 1 (WMRB only)   for every window t, in order:   all-gather(V rows of t)  ->  scores of t
         hinge                local
-        walk 2               for every window t, in order:   broadcast(V rows of t)  ->  user-gradient partial of t,
-                                                             raw item gradient of t  ->  reduce(sum) into the owner
-        U <- fresh-Adam      local;      V rows <- fresh-Adam on the owner, after its windows were broadcast for the last time
+        walk 2               for every window t, in order:   all-gather(V rows of t)  ->  user-gradient partial of t,
+                                                             raw item gradient of t   ->  reduce-scatter(sum) to the owners
+        U <- fresh-Adam      local;      owned V rows <- fresh-Adam, after every window went out for the last time
         all-reduce           2 doubles   (sum of losses, count)
 
-    The broadcast of window t+1 and the reduce of window t-1 are in flight while window t computes (two staging buffers
-    each; the collectives are asynchronous on the RCCL stream).  Sized at the window, not the table: xGMI is point-to-point
-    (7 links x ~153 GB/s per GPU), a broadcast keeps the owner's seven links busy, so one window of w bytes costs ~w / 153 GB/s
-    and the whole table crosses once per walk - overlapped with that walk's compute.
+    The all-gather of window t+1 and the reduce-scatter of window t-1 are in flight while window t computes (two staging
+    buffers each; the collectives are asynchronous on the RCCL stream).  Why interleaved ownership and not one owner per
+    window: xGMI is point-to-point (7 links x ~153 GB/s per GPU).  With one owner a window of w bytes leaves through that GPU's
+    links only - every receiver gets it over ONE link, w / 153 GB/s; with every rank holding 1/world of the window all links
+    of all GPUs carry w / world each, world times faster - the same reason the replicated path uses reduce-scatter + all-gather
+    rather than reduce + broadcast.  The table crosses the fabric once per walk, overlapped with that walk's compute.
     ``backend``: V_own(), two_phase, scores_window(t, Vwin), between(), grads_window(t, Vwin, out), finish_users(),
     adam_rows(W, G) - teamoflow_amd._windowed.WindowedHipBackend on the GPU, the NumPy oracle in tests/test_dist_cpu.py."""
 
-    def __init__(self, backend, local_count, windows_per_rank=1, group=None):
+    def __init__(self, backend, local_count, n_windows, group=None):
         self.b, self.group = backend, group
         self.world, self.rank = _world(group)
-        self.q = int(windows_per_rank)
-        self.T = self.world * self.q
+        self.T = int(n_windows)
         own = backend.V_own()
-        if own.shape[0] % self.q:
-            raise ValueError(f'{own.shape[0]} owned rows are not a multiple of windows_per_rank={self.q}')
-        self.rows = own.shape[0] // self.q
-        dev = own.device
-        self.stage = [torch.empty(self.rows, own.shape[1], dtype=own.dtype, device=dev) for _ in range(2)]
-        self.gbuf = [torch.empty(self.rows, own.shape[1], dtype=torch.float32, device=dev) for _ in range(2)]
-        self.g_own = torch.empty(own.shape[0], own.shape[1], dtype=torch.float32, device=dev)
+        if own.shape[0] % self.T:
+            raise ValueError(f'{own.shape[0]} owned rows are not a multiple of the {self.T} windows')
+        self.sub = own.shape[0] // self.T           # owned rows per window
+        self.rows = self.sub * self.world           # rows of a window
+        dev, ld = own.device, own.shape[1]
+        multi = self.world > 1
+        self.stage = [torch.empty(self.rows, ld, dtype=own.dtype, device=dev) for _ in range(2)] if multi else []
+        self.gbuf = [torch.empty(self.rows, ld, dtype=torch.float32, device=dev) for _ in range(2)] if multi else []
+        self.g_own = torch.empty(own.shape[0], ld, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
         self.local_count = float(local_count)
-        self.bytes = dict(broadcast_per_walk=self.T * self.rows * own.shape[1] * own.element_size(),
-                          reduce=self.T * self.rows * own.shape[1] * 4, walks=2 if backend.two_phase else 1)
+        self.bytes = dict(all_gather_per_walk=self.T * self.rows * ld * own.element_size(),
+                          reduce_scatter=self.T * self.rows * ld * 4, walks=2 if backend.two_phase else 1)
 
-    def _fetch(self, t, buf):
-        owner, i = divmod(t, self.q)
-        tensor = self.b.V_own()[i * self.rows:(i + 1) * self.rows] if owner == self.rank else buf
-        return tensor, broadcast_rows(tensor, owner, self.group)
+    def _fetch(self, t):
+        mine = self.b.V_own()[t * self.sub:(t + 1) * self.sub]
+        if self.world == 1:
+            return mine, _Done()      # one rank: the window is its own rows
+        buf = self.stage[t % 2]
+        return buf, all_gather_rows_async(buf, mine, self.group)
 
     def _windows(self):
-        nxt = self._fetch(0, self.stage[0])
+        nxt = self._fetch(0)
         for t in range(self.T):
             cur, handle = nxt
             handle.wait()
             if t + 1 < self.T:
-                nxt = self._fetch(t + 1, self.stage[(t + 1) % 2])
+                nxt = self._fetch(t + 1)
             yield t, cur
 
     def step(self):
@@ -278,15 +285,18 @@ class ItemShardedEpoch:
             b.between()
         pending = [_Done(), _Done()]
         for t, Vwin in self._windows():
-            owner, i = divmod(t, self.q)
-            pending[t % 2].wait()           # the reduce that used this staging buffer two windows ago
-            out = self.g_own[i * self.rows:(i + 1) * self.rows] if owner == self.rank else self.gbuf[t % 2]
+            mine = self.g_own[t * self.sub:(t + 1) * self.sub]
+            if self.world == 1:
+                b.grads_window(t, Vwin, mine)
+                continue
+            pending[t % 2].wait()           # the reduce-scatter that read this staging buffer two windows ago
+            out = self.gbuf[t % 2]
             b.grads_window(t, Vwin, out)
-            pending[t % 2] = reduce_rows_sum(out, owner, self.group)
+            pending[t % 2] = reduce_scatter_sum_async(mine, out, self.group)
         for h in pending:
             h.wait()
         loss_sum = b.finish_users()
-        b.adam_rows(b.V_own(), self.g_own)   # every window of this epoch has been broadcast: the rows may change now
+        b.adam_rows(b.V_own(), self.g_own)   # every window of this epoch has been gathered: the rows may change now
         self.stats[0] = loss_sum.reshape(())
         self.stats[1] = self.local_count
         if self.world > 1:
@@ -295,13 +305,13 @@ class ItemShardedEpoch:
 
 
 def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, windows_per_rank=1, group=None):
-    """``MatrixFactorization.fit`` with item-row-sharded V (``model.shard_items = windows_per_rank``): users are partitioned
-    over the ranks as in ``fit_data_parallel``, the item rows are owned in contiguous blocks and only pass through the
-    other ranks one window at a time (``ItemShardedEpoch``).  Without a process group it is one rank streaming its own
-    table window by window.  Every rank passes the same global inputs (or, with ``model.local_users``, its own users and
-    - ``model.local_items = True`` - only the initial rows of the items it owns).  On return ``user_embedding`` is this
-    rank's user block, ``item_embedding`` its item rows, ``user_block`` / ``item_block`` their global ranges;
-    ``gather_item_embedding`` assembles the catalog where it fits."""
+    """``MatrixFactorization.fit`` with item-row-sharded V (``model.shard_items = q``: world * q windows): users are partitioned
+    over the ranks as in ``fit_data_parallel``; of every catalog window each rank owns one sub-block of rows, and the windows
+    only pass through the ranks one at a time (``ItemShardedEpoch``).  Without a process group it is one rank streaming its
+    own table window by window.  Every rank passes the same global inputs (or, with ``model.local_users``, its own users and
+    - ``model.local_items = True`` - only the initial rows ``owned_item_rows`` < n_items names, in that order).  On return
+    ``user_embedding`` is this rank's user block (``user_block``), ``item_embedding`` its item rows (``item_rows``: their
+    global ids); ``gather_item_embedding`` assembles the catalog where it fits."""
     import timeit
     from ._windowed import WindowedHipBackend, pad_table, window_geometry
     from .mf.loss_graphs import WMRBLoss
@@ -311,10 +321,10 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     world, rank = _world(group)
     dev = interactions.device
     wmrb = isinstance(model.loss_graph, WMRBLoss)
-    q = max(1, int(windows_per_rank))
+    T = world * max(1, int(windows_per_rank))
     r, dtype = model.n_components, model.factor_dtype
     ld = _lib.padded_ld(r, dtype)
-    rows, _, n_pad = window_geometry(n_items, world * q, ld, 2 if dtype is torch.bfloat16 else 4)
+    rows, _, n_pad = window_geometry(n_items, T, ld, 2 if dtype is torch.bfloat16 else 4, world)
     local = getattr(model, 'local_users', None)
     if local is not None:
         b, e = int(local[0]), int(local[1])
@@ -337,21 +347,23 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
         if R.numel() and (int(R.min()) < 0 or int(R.max()) >= n_items):
             raise IndexError('random_ind holds item ids outside [0, n_items)')
         c = model.n_items / model.n_samples
-    i0, i1 = rank * q * rows, (rank + 1) * q * rows          # owned rows of the padded catalog
+    mine = owned_item_rows(rows, T, world, rank, dev)          # global ids of the owned rows of the padded catalog
+    valid = mine < n_items
     V0 = torch.as_tensor(V0).detach()
-    V_own = torch.zeros(q * rows, ld, dtype=dtype, device=dev)
+    V_own = torch.zeros(mine.numel(), ld, dtype=dtype, device=dev)
     if getattr(model, 'local_items', False):
-        if V0.shape[0] != max(0, min(i1, n_items) - i0):
-            raise ValueError(f'local_items: the item initialiser must return the {max(0, min(i1, n_items) - i0)} rows this rank owns')
-        V_own[:V0.shape[0]] = pad_table(V0, ld, dtype, dev, r)
-    elif i0 < n_items:
-        V_own[:min(i1, n_items) - i0] = pad_table(V0[i0:min(i1, n_items)], ld, dtype, dev, r)
+        if V0.shape[0] != int(valid.sum()):
+            raise ValueError(f'local_items: the item initialiser must return the {int(valid.sum())} rows this rank owns')
+        V_own[valid] = pad_table(V0, ld, dtype, dev, r)
+    else:
+        V_own[valid] = pad_table(V0.to(dev)[mine[valid]], ld, dtype, dev, r)
     U_blk = torch.as_tensor(U0).detach()
     if local is not None and U_blk.shape[0] != e - b:
         raise ValueError(f'local_users = {local}: the user initialiser must return the {e - b} rows of this block')
     U_blk = U_blk if local is not None else U_blk[b:e]
-    backend = WindowedHipBackend(U_blk, V_own, idx, val, R, e - b, n_items, world * q, r, 'wmrb' if wmrb else 'mse', c, lr, dtype=dtype)
-    ep = ItemShardedEpoch(backend, backend.n_loss, windows_per_rank=q, group=group)
+    backend = WindowedHipBackend(U_blk, V_own, idx, val, R, e - b, n_items, T, r, 'wmrb' if wmrb else 'mse', c, lr, dtype=dtype,
+                                 world=world)
+    ep = ItemShardedEpoch(backend, backend.n_loss, T, group=group)
     losses = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
     t0 = timeit.default_timer()
@@ -361,10 +373,11 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     torch.cuda.synchronize(dev)
     model.fit_seconds_ = timeit.default_timer() - t0
     model.loss_history_ = losses[:epochs].cpu().tolist()
-    model._state, model.user_block, model.item_block = backend, (b, e), (min(i0, n_items), min(i1, n_items))
+    model._state, model.user_block, model.item_rows = backend, (b, e), mine[valid]
     model._sharded_epoch, model._n_items_fit = ep, n_items
     model.user_embedding = backend.U[:, :r]
-    model.item_embedding = V_own[:max(0, min(i1, n_items) - i0), :r]
+    # one rank: the owned rows are the catalog in order (a view); several: the valid owned rows, in item_rows order (a copy)
+    model.item_embedding = V_own[:n_items, :r] if world == 1 else V_own[valid][:, :r]
     model.user_trainable, model.item_trainable = [model.user_embedding], [model.item_embedding]
 
 
@@ -400,13 +413,15 @@ def sharded_top_items(model, k, clamp_negatives=False, users=None):
 
 
 def gather_item_embedding(model, n_items, group=None):
-    """Full [n_items, r] item table from the owned blocks (for catalogs that fit after all: tests, export)."""
+    """Full [n_items, r] item table from the owned sub-blocks (for catalogs that fit after all: tests, export)."""
     world, rank = _world(group)
+    ep = model._sharded_epoch
     mine = model._state.V_shard[:, :model.n_components].float().contiguous()
     if world == 1:
         return mine[:n_items]
     out = torch.empty(world * mine.shape[0], mine.shape[1], dtype=torch.float32, device=mine.device)
-    all_gather_rows(out, mine, group)
+    all_gather_rows(out, mine, group)                       # [rank][window][sub-block row]
+    out = out.view(world, ep.T, ep.sub, -1).permute(1, 0, 2, 3).reshape(ep.T * ep.rows, -1)   # catalog order
     return out[:n_items]
 
 

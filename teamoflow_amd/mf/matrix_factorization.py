@@ -470,9 +470,9 @@ class MatrixFactorization:
         (``allow_pickle=True`` here AND in ``load``).  ``include_samples=False`` leaves the [m, S] negative table out."""
         ep = getattr(self, '_sharded_epoch', None)
         if ep is not None and ep.world > 1:
-            raise ValueError('item-row-sharded model: this rank holds users %s and item rows %s only - assemble the tables first '
-                             '(dist.gather_user_embedding / gather_item_embedding) or save one file per rank from them'
-                             % (self.user_block, self.item_block))
+            raise ValueError('item-row-sharded model: this rank holds users %s and %d of the item rows only - assemble the tables '
+                             'first (dist.gather_user_embedding / gather_item_embedding) or save one file per rank from them'
+                             % (self.user_block, int(self.item_rows.numel())))
         _save_to_disk(self, path, include_samples, allow_pickle)
 
     @classmethod

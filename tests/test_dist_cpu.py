@@ -131,8 +131,8 @@ def test_partition_with_more_ranks_than_users_and_empty_plans():
 
 
 # ------------------------------------------------------------------------------------------------
-# Item-row-sharded V (dist.ItemShardedEpoch): no rank holds the table; windows are broadcast from their owner,
-# the item gradient of a window is reduced into its owner, which alone updates those rows.
+# Item-row-sharded V (dist.ItemShardedEpoch): no rank holds the table; every rank owns one sub-block of every window, a
+# window is assembled by all-gather, its item gradient goes back by reduce-scatter and each rank updates its own rows.
 # ------------------------------------------------------------------------------------------------
 class WindowedOracleBackend:
     """Oracle closed forms behind the window interface.  MSE is evaluated window by window from the rows the epoch hands
@@ -211,12 +211,13 @@ def _sharded_worker(rank, world, port, loss, q, out):
     idx_l = idx[sel].copy()
     idx_l[:, 0] -= b
     T = world * q
-    rows = -(-n // T)
+    rows = -(-(-(-n // T)) // world) * world                 # a window splits into `world` equal sub-blocks
     V_pad = np.zeros((rows * T, r), np.float32)
     V_pad[:n] = V0
-    own = V_pad[rank * q * rows:(rank + 1) * q * rows]
+    mine = tdist.owned_item_rows(rows, T, world, rank).numpy()
+    own = V_pad[mine]
     backend = WindowedOracleBackend(U0[b:e], own, idx_l, val[sel], R[b:e], n, Sn, lr, loss, rows, T)
-    ep = tdist.ItemShardedEpoch(backend, local_count=int(sel.sum()), windows_per_rank=q)
+    ep = tdist.ItemShardedEpoch(backend, local_count=int(sel.sum()), n_windows=T)
     losses = [float(ep.step()) for _ in range(3)]
     U, V = U0.copy(), V0.copy()
     ref_losses = []
@@ -228,15 +229,15 @@ def _sharded_worker(rank, world, port, loss, q, out):
         ref_losses.append(l)
     V_ref = np.zeros_like(V_pad)
     V_ref[:n] = V
-    mine = backend.V_own().numpy()
-    lo = rank * q * rows
+    got = backend.V_own().numpy()
     walk = [('scores', t) for t in range(T)] + [('hinge',)] if loss == 'wmrb' else []
     ok = (np.allclose(losses, ref_losses, rtol=1e-5)
           and np.abs(backend.U - U[b:e]).max() < 5e-3 * lr + 1e-6
-          and np.abs(mine - V_ref[lo:lo + q * rows]).max() < 5e-2 * lr + 1e-6
-          and np.all(mine[max(0, n - lo):] == 0)                                  # padding rows stay zero
+          and np.abs(got - V_ref[mine]).max() < 5e-2 * lr + 1e-6
+          and np.all(got[mine >= n] == 0)                                         # padding rows stay zero
           and backend.log[:len(walk) + T] == walk + [('grads', t) for t in range(T)]   # every window once per walk, in order
-          and ep.stage[0].shape[0] == rows and len(ep.stage) == 2)                # two staging windows, never the table
+          and ep.stage[0].shape[0] == rows and len(ep.stage) == 2                 # two staging windows, never the table
+          and got.shape[0] == rows * T // world)
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -1,7 +1,7 @@
 """Item-row-sharded V on the MI355X (teamoflow_amd/dist.py ItemShardedEpoch + _windowed.WindowedHipBackend; SURVEY.md §8e
 "when V no longer fits").  One rank without a process group streams its own table window by window - the same kernels and
 launch sequence every rank of a sharded job runs - and must reproduce the oracle step and the resident fit; two ranks on one
-card (gloo, host-staged collectives) add the window broadcasts and the per-window reduce into the owner."""
+card (gloo, host-staged collectives) add the per-window all-gather and the reduce-scatter of the window's gradient."""
 import json
 import os
 import socket
@@ -73,7 +73,7 @@ def test_windowed_step_against_oracle(tm, monkeypatch, loss, windows, slice_byte
     m, n, Sn, lr = 157, 203, 31, 0.05
     idx, val, U0, V0, R = problem(windows, m, n, r, Sn)
     model = fit(tm, U0, V0, idx, val, (m, n), 1, lr, loss, R, Sn, windows)
-    assert model._state.T == windows and model._state.n_pad >= n and model.item_block == (0, n)
+    assert model._state.T == windows and model._state.n_pad >= n and model.item_rows.tolist() == list(range(n))
     if slice_bytes < 4096:
         assert model._state.k > 1                                   # windows of several slices
     U64, V64 = U0.astype(np.float64), V0.astype(np.float64)
@@ -161,8 +161,8 @@ def test_window_outside_the_resident_rows_is_never_read(tm, monkeypatch):
 @pytest.mark.parametrize('loss,q', [('mse', 1), ('wmrb', 1), ('wmrb', 2)])
 def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
     """Two ranks on cuda:0 (gloo group, host-staged collectives - tools/dp_rehearsal.py with q windows per rank): each owns
-    half of the padded catalog, receives the other half window by window, and the per-window reduce hands every owner the
-    summed gradient of its rows.  Against the single-process resident fit: same loss trajectory, tables equal except
+    half of every catalog window, the windows are assembled by all-gather one at a time, and the per-window reduce-scatter
+    hands every owner the summed gradient of its rows.  Against the single-process resident fit: same loss trajectory, tables equal except
     where a gradient element is ~0 (different summation order)."""
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
@@ -178,8 +178,7 @@ def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
     res = json.loads(out.read_text())
     (b0, e0), (b1, e1) = res['blocks']
     assert b0 == 0 and e0 == b1 and e1 == 3001 and 0 < e0 < 3001
-    (i0, i1), (j0, j1) = res['item_blocks']
-    assert i0 == 0 and i1 == j0 and j1 == 701 and 0 < i1 < 701          # the catalog is split, nobody owns all of it
+    assert res['item_rows_partition_the_catalog'] and all(0 < c < 701 for c in res['item_rows_per_rank'])   # split, nobody owns all
     assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-6 * abs(res['loss_one'][0])
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
     assert res["sharded_top10_equals_resident"] is True

@@ -71,14 +71,15 @@ def main():
         topk_equal = all(same)
     blocks = [None] * world
     dist.all_gather_object(blocks, dp.user_block)
-    item_blocks = [None] * world
-    dist.all_gather_object(item_blocks, getattr(dp, 'item_block', None))
+    item_rows = [None] * world
+    dist.all_gather_object(item_rows, dp.item_rows.cpu().tolist() if shard else None)
     if rank == 0:
         one, one1 = run(False), run(False, 1)
         res = {'U1_equal': bool(torch.equal(U_dp1, one1.user_embedding)),
                'U1_frac_close': float(((U_dp1 - one1.user_embedding).abs() <= 1e-6).float().mean()),
                'U1_max_abs_diff': float((U_dp1 - one1.user_embedding).abs().max()),
-               'item_blocks': item_blocks, 'shard_items': shard, 'sharded_top10_equals_resident': topk_equal,
+               'item_rows_per_rank': [len(x) for x in item_rows] if shard else None,
+               'item_rows_partition_the_catalog': sorted(sum(item_rows, [])) == list(range(n)) if shard else None, 'shard_items': shard, 'sharded_top10_equals_resident': topk_equal,
                'V1_frac_close': float(((dp1.item_embedding - one1.item_embedding).abs() <= 1e-6).float().mean()),
                'V1_max_abs_diff': float((dp1.item_embedding - one1.item_embedding).abs().max()),
                'world': world, 'loss': loss, 'blocks': blocks,

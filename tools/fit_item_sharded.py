@@ -5,7 +5,7 @@
   TMF_BENCH_REHEARSE=1: every rank on card 0 with a gloo group (host-staged collectives; timings mean nothing).
 
 Every rank draws its own M users (weak scaling, like bench.py) and passes them with model.local_users; the item table
-is owned in row blocks (model.local_items: a rank initialises only its rows).  Rank 0 prints one JSON line: ms per epoch
+is owned in sub-blocks of every window (model.local_items: a rank initialises only the rows dist.owned_item_rows names).  Rank 0 prints one JSON line: ms per epoch
 (max over ranks), interactions/s of the whole job, bytes each walk moves per rank."""
 import argparse
 import json
@@ -19,6 +19,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from teamoflow_amd import _lib, _windowed  # noqa: E402
+from teamoflow_amd import dist as tdist  # noqa: E402
 from teamoflow_amd.mf.initializer_graphs import FixedInitializer, Initializer  # noqa: E402
 from teamoflow_amd.mf.loss_graphs import MSELoss, WMRBLoss  # noqa: E402
 from teamoflow_amd.mf.matrix_factorization import MatrixFactorization  # noqa: E402
@@ -60,11 +61,12 @@ def main():
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     idx, val = bench.gen_interactions(m, n, args.nnz, 'zipf', rank, dev)
     ld = _lib.padded_ld(r, dtype)
-    rows, _, _ = _windowed.window_geometry(n, world * q, ld, 2 if dtype is torch.bfloat16 else 4)
-    i0, i1 = min(rank * q * rows, n), min((rank + 1) * q * rows, n)
+    rows, _, _ = _windowed.window_geometry(n, world * q, ld, 2 if dtype is torch.bfloat16 else 4, world)
+    mine = tdist.owned_item_rows(rows, world * q, world, rank, dev)
+    mine = mine[mine < n]
     V_all = bench.init_table(n, r, 7, dev)                    # same seed everywhere; only the owned rows are kept
     kw = dict(user_weight_graph=FixedInitializer(bench.init_table(m, r, 11 + rank, dev)),
-              item_weight_graph=OwnedRows(V_all[i0:i1].clone()))
+              item_weight_graph=OwnedRows(V_all[mine].clone()))
     del V_all
     if args.loss == 'wmrb':
         kw.update(loss_graph=WMRBLoss(), n_users=m, n_items=n, n_samples=S)
@@ -93,9 +95,9 @@ def main():
         print(json.dumps(dict(metric='train_interactions_per_sec', value=float(t[1]) / sec, unit='interactions/s', n_gpus=world,
                               ms_per_epoch=sec * 1e3, epochs=args.epochs, windows_per_rank=q, window_rows=rows,
                               plan_seconds=model.plan_seconds_, wall_seconds=wall, loss_first_last=[model.loss_history_[0], model.loss_history_[-1]],
-                              item_block_rank0=list(model.item_block),
-                              per_rank_per_epoch=dict(broadcast_bytes_received=(2 if args.loss == 'wmrb' else 1) * (world - 1) * q * rows * ld * esz,
-                                                      reduce_bytes=world * q * rows * ld * 4),
+                              item_rows_rank0=int(model.item_rows.numel()),
+                              per_rank_per_epoch=dict(all_gather_bytes_received=(2 if args.loss == 'wmrb' else 1) * (world - 1) * q * rows * ld * esz,
+                                                      reduce_scatter_bytes_sent=(world - 1) * q * rows * ld * 4),
                               data='synthetic' + (' (REHEARSAL on one card: timings invalid)' if rehearse else ''),
                               config=dict(workload=f'{m} users x {n} items per rank, r={r}, {args.loss.upper()}, item rows sharded over {world} rank(s)'))))
     if world > 1:
