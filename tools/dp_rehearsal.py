@@ -48,6 +48,8 @@ def main():
             kw.update(loss_graph=MSELoss())
         model = MatrixFactorization(r, **kw)
         model.verbose, model.data_parallel = False, parallel and not shard
+        if os.environ.get('TMF_REHEARSE_DTYPE') == 'bf16':     # config 5's storage: bf16 rows cross the wire, fp32 gradients
+            model.factor_dtype = torch.bfloat16
         model.shard_items = shard if parallel else 0
         if loss == 'wmrb':
             model.random_ind = torch.as_tensor(R)
@@ -65,7 +67,7 @@ def main():
     if shard:
         # ranking over the sharded catalog == ranking the assembled tables with the resident fused kernel, exactly
         from teamoflow_amd import _ops
-        mine = _ops.predict_topk(dp.user_embedding, dp.item_embedding, 10, clamp_negatives=True)
+        mine = _ops.predict_topk(dp.user_embedding, dp.item_embedding.to(dp.user_embedding.dtype), 10, clamp_negatives=True)
         same = [None] * world
         dist.all_gather_object(same, bool(torch.equal(mine, dp.top10_sharded)))
         topk_equal = all(same)
@@ -75,6 +77,9 @@ def main():
     dist.all_gather_object(item_rows, dp.item_rows.cpu().tolist() if shard else None)
     if rank == 0:
         one, one1 = run(False), run(False, 1)
+        f32 = lambda m: (m.user_embedding.float(), m.item_embedding.float())   # noqa: E731
+        (one.user_embedding, one.item_embedding), (one1.user_embedding, one1.item_embedding) = f32(one), f32(one1)
+        dp.item_embedding, dp1.item_embedding = dp.item_embedding.float(), dp1.item_embedding.float()
         res = {'U1_equal': bool(torch.equal(U_dp1, one1.user_embedding)),
                'U1_frac_close': float(((U_dp1 - one1.user_embedding).abs() <= 1e-6).float().mean()),
                'U1_max_abs_diff': float((U_dp1 - one1.user_embedding).abs().max()),
