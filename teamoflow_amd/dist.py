@@ -241,9 +241,12 @@ class ItemShardedEpoch:
     ``backend``: V_own(), two_phase, scores_window(t, Vwin), between(), grads_window(t, Vwin, out), finish_users(),
     adam_rows(W, G) - teamoflow_amd._windowed.WindowedHipBackend on the GPU, the NumPy oracle in tests/test_dist_cpu.py."""
 
-    def __init__(self, backend, local_count, n_windows, group=None):
+    def __init__(self, backend, local_count, n_windows, group=None, always_collective=False):
         self.b, self.group = backend, group
         self.world, self.rank = _world(group)
+        # always_collective: run the all-gather / reduce-scatter even with one rank (a test of the asynchronous RCCL path on
+        # one GPU: staging buffers, stream ordering, dtypes); otherwise one rank reads and writes its own rows directly
+        self.collective = self.world > 1 or (bool(always_collective) and dist.is_available() and dist.is_initialized())
         self.T = int(n_windows)
         own = backend.V_own()
         if own.shape[0] % self.T:
@@ -251,7 +254,7 @@ class ItemShardedEpoch:
         self.sub = own.shape[0] // self.T           # owned rows per window
         self.rows = self.sub * self.world           # rows of a window
         dev, ld = own.device, own.shape[1]
-        multi = self.world > 1
+        multi = self.collective
         self.stage = [torch.empty(self.rows, ld, dtype=own.dtype, device=dev) for _ in range(2)] if multi else []
         self.gbuf = [torch.empty(self.rows, ld, dtype=torch.float32, device=dev) for _ in range(2)] if multi else []
         self.g_own = torch.empty(own.shape[0], ld, dtype=torch.float32, device=dev)
@@ -262,7 +265,7 @@ class ItemShardedEpoch:
 
     def _fetch(self, t):
         mine = self.b.V_own()[t * self.sub:(t + 1) * self.sub]
-        if self.world == 1:
+        if not self.collective:
             return mine, _Done()      # one rank: the window is its own rows
         buf = self.stage[t % 2]
         return buf, all_gather_rows_async(buf, mine, self.group)
@@ -286,7 +289,7 @@ class ItemShardedEpoch:
         pending = [_Done(), _Done()]
         for t, Vwin in self._windows():
             mine = self.g_own[t * self.sub:(t + 1) * self.sub]
-            if self.world == 1:
+            if not self.collective:
                 b.grads_window(t, Vwin, mine)
                 continue
             pending[t % 2].wait()           # the reduce-scatter that read this staging buffer two windows ago
@@ -363,7 +366,7 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     U_blk = U_blk if local is not None else U_blk[b:e]
     backend = WindowedHipBackend(U_blk, V_own, idx, val, R, e - b, n_items, T, r, 'wmrb' if wmrb else 'mse', c, lr, dtype=dtype,
                                  world=world)
-    ep = ItemShardedEpoch(backend, backend.n_loss, T, group=group)
+    ep = ItemShardedEpoch(backend, backend.n_loss, T, group=group, always_collective=getattr(model, 'shard_always_collective', False))
     losses = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
     t0 = timeit.default_timer()

@@ -312,3 +312,34 @@ def test_two_ranks_item_sharded_bf16_rows(tmp_path):
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-3
     assert res['U1_frac_close'] > 0.97 and res['V1_frac_close'] > 0.97
     assert res['U1_max_abs_diff'] <= 2.0 * 0.05 + 0.01 and res['V1_max_abs_diff'] <= 2.0 * 0.05 + 0.01
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_one_rank_rccl_collectives_give_the_same_bits(tm, dtype):
+    """The asynchronous RCCL path of the sharded epoch on this one GPU: with a 1-rank nccl group and
+    model.shard_always_collective the windows really go through all_gather_into_tensor into the staging buffers and the
+    gradients through reduce_scatter_tensor (both async on the communicator's stream, ordered by handle.wait()).  Bits must equal
+    the direct one-rank fit - any missing stream dependency or stale staging buffer would show."""
+    import torch.distributed as dist
+    m, n, r, Sn, lr = 257, 331, 32, 24, 0.05
+    idx, val, U0, V0, R = problem(21, m, n, r, Sn)
+    base = {loss: fit(tm, U0, V0, idx, val, (m, n), 4, lr, loss, R, Sn, 5, dtype=dtype) for loss in ('mse', 'wmrb')}
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29543')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        for loss in ('mse', 'wmrb'):
+            kw = dict(user_weight_graph=tm.Fixed(U0), item_weight_graph=tm.Fixed(V0))
+            if loss == 'wmrb':
+                kw.update(loss_graph=tm.WMRB(), n_users=m, n_items=n, n_samples=Sn)
+            model = tm.MF(r, **kw)
+            model.random_ind = torch.as_tensor(R)
+            model.verbose, model.shard_items, model.factor_dtype, model.shard_always_collective = False, 5, dtype, True
+            model.fit(4, tm.eye(m), tm.eye(n), tm.Sparse(idx, val, (m, n)), lr=lr)
+            assert model._sharded_epoch.collective and len(model._sharded_epoch.stage) == 2
+            assert model.loss_history_ == base[loss].loss_history_
+            assert torch.equal(model.item_embedding, base[loss].item_embedding)
+            assert torch.equal(model.user_embedding, base[loss].user_embedding)
+    finally:
+        dist.destroy_process_group()
