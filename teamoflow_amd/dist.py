@@ -491,6 +491,19 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
     model.user_trainable, model.item_trainable = [model.user_embedding], [model.item_embedding]
 
 
+def mean_recall_at_k(model, local_interactions, k=10, group=None):
+    """Mean recall@k over ALL users of a multi-GPU fit (SURVEY.md §8e "predict / recall": user-partitioned, the final mean is a
+    2-float all-reduce).  ``local_interactions``: this rank's users (ids relative to ``model.user_block[0]``) against the whole
+    catalog.  Each rank ranks its own users - against the replicated table (``fit_data_parallel``) or window by window
+    (``fit_item_sharded``, where the call is a collective anyway) - and only (sum of recalls, number of users with
+    positives) crosses the wire.  Returns a Python float, the same on every rank."""
+    rec = model.recall_at_k(local_interactions, k=k)             # users with at least one positive (matrix_factorization.py:255-258)
+    stats = torch.stack([rec.double().sum(), torch.tensor(float(rec.numel()), dtype=torch.float64, device=rec.device)])
+    if _world(group)[0] > 1:
+        all_reduce_sum(stats, group)
+    return float(stats[0] / stats[1]) if float(stats[1]) else float('nan')
+
+
 def gather_user_embedding(model, n_users, group=None):
     """Full [n_users, r] user table from the per-rank blocks (blocks are padded to the largest one)."""
     world = dist.get_world_size(group)

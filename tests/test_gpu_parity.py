@@ -671,6 +671,8 @@ def test_two_ranks_on_one_card_match_single_process(tmp_path, loss, knobs):
     assert b0 == 0 and e0 == b1 and e1 == 3001 and 0 < e0 < 3001
     assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-9 * abs(res['loss_one'][0])   # same weights, same data
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
+    # mean recall@10 over all users = 2-double all-reduce of per-rank (sum, count); equals ranking the assembled tables
+    assert abs(res['recall_all_ranks'] - res['recall_assembled_tables']) <= 1e-12 and 0 < res['recall_all_ranks'] < 1
     assert res['U1_equal']                       # after one epoch the user table is bit-identical
     assert res['V1_frac_close'] > 0.99           # item rows: two partial sums instead of one; |diff| <= 1e-6 except where g ~ 0
     assert res['V1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6

@@ -182,6 +182,7 @@ def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
     assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-6 * abs(res['loss_one'][0])
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
     assert res["sharded_top10_equals_resident"] is True
+    assert abs(res['recall_all_ranks'] - res['recall_assembled_tables']) <= 1e-12 and 0 < res['recall_all_ranks'] < 1
     assert res['U1_frac_close'] > 0.99 and res['U1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
     assert res['V1_frac_close'] > 0.99 and res['V1_max_abs_diff'] <= 2.0 * 0.05 + 1e-6
 
@@ -308,6 +309,7 @@ def test_two_ranks_item_sharded_bf16_rows(tmp_path):
     assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
     res = json.loads(out.read_text())
     assert res['sharded_top10_equals_resident'] is True and res['item_rows_partition_the_catalog']
+    assert abs(res['recall_all_ranks'] - res['recall_assembled_tables']) <= 1e-12
     assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-6 * abs(res['loss_one'][0])
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-3
     assert res['U1_frac_close'] > 0.97 and res['V1_frac_close'] > 0.97

@@ -71,6 +71,16 @@ def main():
         same = [None] * world
         dist.all_gather_object(same, bool(torch.equal(mine, dp.top10_sharded)))
         topk_equal = all(same)
+    # mean recall@10 over all users: every rank ranks its own users, two doubles are all-reduced
+    b_, e_ = dp.user_block
+    sel = (idx[:, 0] >= b_) & (idx[:, 0] < e_)
+    loc = idx[sel].copy()
+    loc[:, 0] -= b_
+    saved = dp.item_embedding
+    if shard:
+        dp.item_embedding = None         # a sharded model must not touch a table here: it ranks over the windows
+    recall_all = tdist.mean_recall_at_k(dp, SparseInteractions(loc, val[sel], (e_ - b_, n)))
+    dp.item_embedding = saved
     blocks = [None] * world
     dist.all_gather_object(blocks, dp.user_block)
     item_rows = [None] * world
@@ -80,7 +90,12 @@ def main():
         f32 = lambda m: (m.user_embedding.float(), m.item_embedding.float())   # noqa: E731
         (one.user_embedding, one.item_embedding), (one1.user_embedding, one1.item_embedding) = f32(one), f32(one1)
         dp.item_embedding, dp1.item_embedding = dp.item_embedding.float(), dp1.item_embedding.float()
-        res = {'U1_equal': bool(torch.equal(U_dp1, one1.user_embedding)),
+        # the same number from the assembled tables in one process
+        whole = run(False, 0)
+        whole.user_embedding, whole.item_embedding = U_dp.to(dp.user_embedding.dtype), dp.item_embedding.to(dp.user_embedding.dtype)
+        recall_ref = float(whole.recall_at_k(SparseInteractions(idx, val, (m, n))).double().mean())
+        res = {'recall_all_ranks': recall_all, 'recall_assembled_tables': recall_ref,
+               'U1_equal': bool(torch.equal(U_dp1, one1.user_embedding)),
                'U1_frac_close': float(((U_dp1 - one1.user_embedding).abs() <= 1e-6).float().mean()),
                'U1_max_abs_diff': float((U_dp1 - one1.user_embedding).abs().max()),
                'item_rows_per_rank': [len(x) for x in item_rows] if shard else None,
