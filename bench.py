@@ -576,6 +576,8 @@ def main():
                            interactions_per_gpu=wl.nnz, interactions_total=nnz_total, positives_per_gpu=wl.plan.n_pos,
                            parallelism=f'user-partition dp{world}', lr=args.lr, warmup_ms_per_step=warm_elapsed / max(args.warmup, 1) * 1e3),
                roofline=roofline)
+    if args.loss == 'wmrb':   # hinge terms per second = positives x negatives per user / epoch time
+        out['hinge_terms_per_sec'] = float(wl.plan.n_pos) * wl.S * world / (elapsed / args.steps)
     if comm is not None:
         out['collectives'] = comm
 
@@ -584,6 +586,10 @@ def main():
         losses = loss_buf[:args.steps + args.warmup].cpu().numpy() / denom
         out['loss_first_last'] = [float(losses[0]), float(losses[-1])]
         out['cpu_baseline'] = cpu_baseline(args.loss, wl.idx, wl.val, wl.R, wl.U0, wl.V0[:wl.n], wl.n, wl.S, args.lr)
+        # context: what the reference's dense formulation of this epoch would cost - forward + two backward
+        # matmuls of [m, n, r] - it cannot run at this size (the [m, n] score matrix alone is 4 m n bytes)
+        out['cpu_baseline']['reference_dense_formulation'] = dict(flops_per_epoch=6.0 * wl.m * wl.n * wl.r,
+                                                                  score_matrix_bytes=4.0 * wl.m * wl.n)
         # predict rows/s: stable top-10 over the full catalog, fused GEMM + top-k (no [m, n] matrix)
         Ue, Ve = wl.st.U[:, :wl.r], wl.st.V[:wl.n, :wl.r]
         rows = min(wl.m, 262144)
