@@ -345,3 +345,21 @@ def test_one_rank_rccl_collectives_give_the_same_bits(tm, dtype):
             assert torch.equal(model.user_embedding, base[loss].user_embedding)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+@pytest.mark.parametrize('r', [16, 100, 256])
+def test_windowed_bf16_follows_resident_bf16(tm, loss, r):
+    """bf16 storage, both losses, across row geometries: one epoch in 3 windows against the resident bf16 fit from the same
+    (bf16-representable) start - same loss to fp32 summation order, tables equal except where a differently ordered fp32 sum
+    rounds to the neighbouring bf16 value."""
+    m, n, Sn, lr = 150, 190, 20, 0.05
+    idx, val, U0, V0, R = problem(31 + r, m, n, r, Sn)
+    rb = lambda x: torch.tensor(x).bfloat16().float().numpy()   # noqa: E731
+    U0, V0 = rb(U0), rb(V0)
+    a = fit(tm, U0, V0, idx, val, (m, n), 1, lr, loss, R, Sn, 3, dtype=torch.bfloat16)
+    b = fit(tm, U0, V0, idx, val, (m, n), 1, lr, loss, R, Sn, 0, dtype=torch.bfloat16)
+    assert abs(a.loss_history_[0] - b.loss_history_[0]) <= 2e-6 * abs(b.loss_history_[0])
+    for x, y in ((a.user_embedding, b.user_embedding), (a.item_embedding, b.item_embedding)):
+        d = (x.float() - y.float()).abs()
+        assert float((d == 0).float().mean()) > 0.97 and float(d.max()) <= 2 * lr + 0.01
