@@ -27,7 +27,9 @@ def window_geometry(n_items, n_windows, ld, elem_size, world=1):
     stay zero)."""
     import math
     rows = max(1, -(-n_items // n_windows))
-    k = int(min(max(1, -(-rows * ld * elem_size // WINDOW_SLICE_BYTES)), max(1, 256 // n_windows)))
+    # at most 64 slices over the whole catalog, like the resident pass (_engine.default_item_slices): shorter (user, slice)
+    # ranges than that are bound by the walk, not by where the rows come from (config-5 shard: 128 slices 288 ms, 64 255 ms)
+    k = int(min(max(1, -(-rows * ld * elem_size // WINDOW_SLICE_BYTES)), max(1, 64 // n_windows)))
     step = k * world // math.gcd(k, world)
     rows = -(-rows // step) * step
     return rows, k, rows * n_windows
@@ -65,7 +67,9 @@ class WindowedHipBackend:
         self.part = torch.empty(2 * max(m, 1), ld, dtype=torch.float32, device=dev)   # layer 0 sums, layer 1 = one window (MSE)
         if loss == 'wmrb':
             self.plan = _engine.InteractionPlan(indices, values, m, self.n_pad, csc=False)
-            C = user_chunks or _engine.default_user_chunks(m, ld, n_items=self.rows)
+            # user blocks as the resident pass would choose them for the whole catalog: more blocks would fit the slab of one
+            # window but leave a handful of entries per (block, item) list
+            C = user_chunks or _engine.default_user_chunks(m, ld, n_items=self.n_pad)
             self.wplan = w = _engine.WmrbPlan(self.plan, R, user_chunks=C, item_slices=self.T * self.k,
                                               n_components=self.r, sliced=True, item_lists=False)
             self.lists = [w.window_lists(self.plan, t * self.k, self.k, t * self.rows) for t in range(self.T)]
