@@ -1,7 +1,8 @@
 """End-to-end recall@10 on C1 (100 x 50, r=5, MSE, 450 epochs): engine-trained vs oracle-trained tables from the SAME start,
 for the golden fixture's start and for a few other seeds.  With 225 interactions and near-sign Adam steps the two
 trajectories drift apart (loss agrees to ~1e-3 after 450 epochs); this prints how far recall@10 moves.
-usage: python tools/c1_recall_e2e.py"""
+(a checker script, not collected by pytest - it lives under tests/ because only tests may use oracle/)
+usage: python tests/check_c1_recall_e2e.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
