@@ -464,6 +464,80 @@ def api_fit(dev, wl, args, epochs, shard_items=0):
     return out
 
 
+def sharded_run(args, rank, world, dev, rehearse, red_dev, json_out):
+    """--shard-items Q: the same workload with the item table row-sharded over the ranks (every rank owns 1/world of every
+    catalog window; dist.ItemShardedEpoch).  Weak scaling: every rank its own users.  Same timed-region rules as the main path."""
+    from teamoflow_amd import _windowed
+    m, n, r, S = args.users, args.items, args.r, args.samples
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    esz = 2 if args.dtype == 'bf16' else 4
+    T = world * args.shard_items
+    ld = _lib.padded_ld(r, dtype)
+    idx, val = gen_interactions(m, n, args.nnz, args.item_dist, rank, dev)
+    U0 = init_table(m, r, 11 + rank, dev)
+    rows, k, n_pad = _windowed.window_geometry(n, T, ld, esz, world)
+    mine = tdist.owned_item_rows(rows, T, world, rank, dev)
+    valid = mine < n
+    V_own = torch.zeros(mine.numel(), ld, dtype=dtype, device=dev)
+    V_own[valid] = _windowed.pad_table(init_table(n, r, 7, dev)[mine[valid]], ld, dtype, dev, r)
+    R = random_sampler_device(n, m, S, seed=100 + rank, device=dev) if args.loss == 'wmrb' else None
+    backend = _windowed.WindowedHipBackend(U0, V_own, idx, val, R, m, n, T, r, args.loss, n / S if args.loss == 'wmrb' else 0.0, args.lr,
+                                           dtype=dtype, world=world)
+    ep = tdist.ItemShardedEpoch(backend, backend.n_loss, T)
+    multi = world > 1
+    losses = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
+
+    def fence():
+        torch.cuda.synchronize()
+        if multi:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+    fence()
+    tw = time.perf_counter()
+    for i in range(args.warmup):
+        losses[i] = ep.step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses[args.warmup + i] = ep.step()
+    fence()
+    elapsed, warm = time.perf_counter() - t0, t0 - tw
+    nnz_total = float(val.numel())
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+        tot = torch.tensor([nnz_total], dtype=torch.float64, device=red_dev)
+        torch.distributed.all_reduce(tot)
+        nnz_total = float(tot)
+    if rank != 0:
+        return
+    sec = elapsed / args.steps
+    rows_gathered = (3 if args.loss == 'wmrb' else 2) * (m * S * (args.loss == 'wmrb') + float(val.numel()))   # per rank and epoch
+    gather = rows_gathered * ld * esz
+    walks = 2 if args.loss == 'wmrb' else 1
+    lh = losses[:args.steps + args.warmup].cpu().tolist()
+    out = dict(metric='train_interactions_per_sec', value=nnz_total / sec, unit='interactions/s', n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=sec * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32' if args.dtype == 'f32' else 'bf16 storage / f32 arithmetic',
+               data='synthetic' + (' (REHEARSAL: all ranks on one card, host-staged gloo collectives - timings invalid)' if rehearse else ''),
+               config=dict(workload=f'{m} users x {n} items per GPU, r={r}, {args.loss.upper()}' + (f' S={S}' if args.loss == 'wmrb' else '')
+                           + f', ITEM ROWS SHARDED over {world} rank(s): {T} windows of {rows} rows ({k} slices each), every rank owns '
+                             f'{rows // world} rows of every window',
+                           interactions_per_gpu=int(val.numel()), interactions_total=nnz_total, parallelism=f'user-partition dp{world} + item-row-sharded V',
+                           lr=args.lr, warmup_ms_per_step=warm / max(args.warmup, 1) * 1e3),
+               roofline=dict(bound='l2', kernel='whole windowed epoch (per-kernel timers are not wired on this path)', achieved=gather / sec / 1e9,
+                             peak=L2_PEAK / 1e9, unit='GB/s', frac=gather / sec / L2_PEAK, traffic=None,
+                             note='gathered factor-row bytes of the epoch (every row counted once per gather) over the epoch time against the aggregate L2 rate'),
+               collectives=dict(ranks=world, backend=torch.distributed.get_backend() if multi else None, walks_per_epoch=walks,
+                                all_gather_bytes_received_per_rank=walks * (world - 1) * (T * rows // world) * ld * esz,
+                                reduce_scatter_bytes_sent_per_rank=(world - 1) * (T * rows // world) * ld * 4,
+                                note='per window: all-gather of the rows (async, prefetched one window ahead), reduce-scatter of the fp32 '
+                                     'gradient (async); overlapped with the window\'s kernels'),
+               loss_first_last=[lh[0], lh[-1]])
+    print(json.dumps(out), file=json_out, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -482,6 +556,9 @@ def main():
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32', help='factor storage (arithmetic is fp32 either way)')
     ap.add_argument('--small-configs', action='store_true', help='time BASELINE configs 1-3 in full (GPU fit vs dense CPU restatement)')
     ap.add_argument('--no-extras', action='store_true', help='skip cpu baseline / predict / API / HBM legs / small configs')
+    ap.add_argument('--shard-items', type=int, default=0, metavar='Q',
+                    help='item-row-sharded V (BASELINE config 4 as written): Q windows per rank, per-window all-gather / reduce-scatter '
+                         '(dist.ItemShardedEpoch) instead of the replicated table; one JSON line with an epoch-level roofline entry')
     ap.add_argument('--no-legs', action='store_true', help='skip the two HBM-streaming side legs (C4 MSE, config-5 shard)')
     args = ap.parse_args()
 
@@ -517,6 +594,12 @@ def main():
     red_dev = 'cpu' if rehearse else dev   # where the scalar reductions of the report live
     _lib.get()
 
+    if args.shard_items > 0:
+        sharded_run(args, rank, world, dev, rehearse, red_dev, json_out)
+        if dp_mode:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     strong = args.scaling == 'strong'
     wl = Workload(args, args.users, args.items, args.nnz, args.r, args.samples, args.loss, args.dtype, rank, world, dev, strong)
     if rank == 0:
