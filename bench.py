@@ -476,10 +476,11 @@ def sharded_run(args, rank, world, dev, rehearse, red_dev, json_out):
     idx, val = gen_interactions(m, n, args.nnz, args.item_dist, rank, dev)
     U0 = init_table(m, r, 11 + rank, dev)
     rows, k, n_pad = _windowed.window_geometry(n, T, ld, esz, world)
-    mine = tdist.owned_item_rows(rows, T, world, rank, dev)
-    valid = mine < n
-    V_own = torch.zeros(mine.numel(), ld, dtype=dtype, device=dev)
-    V_own[valid] = _windowed.pad_table(init_table(n, r, 7, dev)[mine[valid]], ld, dtype, dev, r)
+    V_own = torch.zeros(T * rows // world, ld, dtype=dtype, device=dev)
+    V_all = init_table(n, r, 7, dev)                                    # same seed on every rank; only the owned rows are kept
+    for l0, g0, cnt in tdist.owned_blocks(rows, T, world, rank, n):
+        V_own[l0:l0 + cnt, :r] = V_all[g0:g0 + cnt]
+    del V_all
     R = random_sampler_device(n, m, S, seed=100 + rank, device=dev) if args.loss == 'wmrb' else None
     backend = _windowed.WindowedHipBackend(U0, V_own, idx, val, R, m, n, T, r, args.loss, n / S if args.loss == 'wmrb' else 0.0, args.lr,
                                            dtype=dtype, world=world)

@@ -210,6 +210,21 @@ def reduce_scatter_sum_async(out, inp, group=None):
     return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
+def owned_blocks(rows_per_window, n_windows, world, rank, n_items):
+    """[(local_begin, global_begin, count)]: the runs of VALID catalog rows (< n_items) that ``rank`` owns - one per window,
+    ``count`` rows from global row ``global_begin`` stored from local row ``local_begin`` on.  Tables are filled and read back
+    with these slices rather than with index gathers (torch's row gather miscomputes offsets on multi-GB tensors here,
+    tools/torch_row_index_probe.py)."""
+    sub = rows_per_window // world
+    out = []
+    for t in range(n_windows):
+        g0 = t * rows_per_window + rank * sub
+        cnt = max(0, min(g0 + sub, n_items) - g0)
+        if cnt:
+            out.append((t * sub, g0, cnt))
+    return out
+
+
 def owned_item_rows(rows_per_window, n_windows, world, rank, device=None):
     """Global row ids (int64, ascending) of the padded catalog that ``rank`` owns: of every window its ``rank``-th
     sub-block of rows_per_window / world rows."""
@@ -316,7 +331,7 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     ``user_embedding`` is this rank's user block (``user_block``), ``item_embedding`` its item rows (``item_rows``: their
     global ids); ``gather_item_embedding`` assembles the catalog where it fits."""
     import timeit
-    from ._windowed import WindowedHipBackend, pad_table, window_geometry
+    from ._windowed import WindowedHipBackend, window_geometry
     from .mf.loss_graphs import WMRBLoss
     t_plan = timeit.default_timer()
     if getattr(model, 'optimizer', 'fresh_adam') != 'fresh_adam':
@@ -351,15 +366,18 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
             raise IndexError('random_ind holds item ids outside [0, n_items)')
         c = model.n_items / model.n_samples
     mine = owned_item_rows(rows, T, world, rank, dev)          # global ids of the owned rows of the padded catalog
-    valid = mine < n_items
+    blocks = owned_blocks(rows, T, world, rank, n_items)       # the same as slices: (local row, global row, count) per window
+    n_valid = sum(cnt for _, _, cnt in blocks)
     V0 = torch.as_tensor(V0).detach()
     V_own = torch.zeros(mine.numel(), ld, dtype=dtype, device=dev)
-    if getattr(model, 'local_items', False):
-        if V0.shape[0] != int(valid.sum()):
-            raise ValueError(f'local_items: the item initialiser must return the {int(valid.sum())} rows this rank owns')
-        V_own[valid] = pad_table(V0, ld, dtype, dev, r)
-    else:
-        V_own[valid] = pad_table(V0.to(dev)[mine[valid]], ld, dtype, dev, r)
+    local_items = bool(getattr(model, 'local_items', False))
+    if local_items and V0.shape[0] != n_valid:
+        raise ValueError(f'local_items: the item initialiser must return the {n_valid} rows this rank owns')
+    given = 0
+    for l0, g0, cnt in blocks:
+        src = V0[given:given + cnt] if local_items else V0[g0:g0 + cnt]
+        V_own[l0:l0 + cnt, :r] = src.to(device=dev, dtype=torch.float32)      # rounds to the table dtype on assignment
+        given += cnt
     U_blk = torch.as_tensor(U0).detach()
     if local is not None and U_blk.shape[0] != e - b:
         raise ValueError(f'local_users = {local}: the user initialiser must return the {e - b} rows of this block')
@@ -376,11 +394,12 @@ def fit_item_sharded(model, epochs, n_users, n_items, interactions, lr, U0, V0, 
     torch.cuda.synchronize(dev)
     model.fit_seconds_ = timeit.default_timer() - t0
     model.loss_history_ = losses[:epochs].cpu().tolist()
-    model._state, model.user_block, model.item_rows = backend, (b, e), mine[valid]
+    model._state, model.user_block, model.item_rows = backend, (b, e), mine[mine < n_items]
     model._sharded_epoch, model._n_items_fit = ep, n_items
     model.user_embedding = backend.U[:, :r]
     # one rank: the owned rows are the catalog in order (a view); several: the valid owned rows, in item_rows order (a copy)
-    model.item_embedding = V_own[:n_items, :r] if world == 1 else V_own[valid][:, :r]
+    model.item_embedding = (V_own[:n_items, :r] if world == 1 else
+                            torch.cat([V_own[l0:l0 + cnt, :r] for l0, _, cnt in blocks]) if blocks else V_own[:0, :r])
     model.user_trainable, model.item_trainable = [model.user_embedding], [model.item_embedding]
 
 

@@ -62,11 +62,10 @@ def main():
     idx, val = bench.gen_interactions(m, n, args.nnz, 'zipf', rank, dev)
     ld = _lib.padded_ld(r, dtype)
     rows, _, _ = _windowed.window_geometry(n, world * q, ld, 2 if dtype is torch.bfloat16 else 4, world)
-    mine = tdist.owned_item_rows(rows, world * q, world, rank, dev)
-    mine = mine[mine < n]
     V_all = bench.init_table(n, r, 7, dev)                    # same seed everywhere; only the owned rows are kept
+    owned = torch.cat([V_all[g0:g0 + cnt] for _, g0, cnt in tdist.owned_blocks(rows, world * q, world, rank, n)])
     kw = dict(user_weight_graph=FixedInitializer(bench.init_table(m, r, 11 + rank, dev)),
-              item_weight_graph=OwnedRows(V_all[mine].clone()))
+              item_weight_graph=OwnedRows(owned))
     del V_all
     if args.loss == 'wmrb':
         kw.update(loss_graph=WMRBLoss(), n_users=m, n_items=n, n_samples=S)
