@@ -50,7 +50,7 @@ class WMRBLoss(LossGraph):
     def get_loss(self, tf_interactions, tf_sample_predictions, tf_prediction_serial, n_items, n_samples,
                  predictions=None):
         mask = tf_interactions.values > 0.0
-        users = tf_interactions.indices[mask][:, 0]
+        users = tf_interactions.indices[:, 0][mask]
         pos = tf_prediction_serial[mask]
         x = 1.0 - pos[:, None] + tf_sample_predictions[users]
         hinge = _TFMaximum.apply(x, torch.zeros_like(x))
