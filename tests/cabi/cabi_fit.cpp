@@ -1,0 +1,197 @@
+// A compiled caller of the C ABI (include/tmf.h) with no Python and no torch in the process: builds the index
+// structures, runs MSE epochs (matrix_factorization.py:130-176 with MSELoss) and a fused predict + top-k on the GPU
+// through libtmf.so, and checks the results against a plain fp64 restatement kept in this file (test infrastructure).
+// Built by tests/cabi/Makefile (hipcc; only the HIP runtime API is used on the host side), run by
+// tests/test_gpu_cabi.py.  Exit code 0 = every check passed.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <set>
+#include <utility>
+#include <vector>
+
+#include "tmf.h"
+
+#define HIP_OK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } \
+    } while (0)
+#define TMF_OK_(x)                                                                        \
+    do {                                                                                  \
+        int rc_ = (x);                                                                    \
+        if (rc_ != TMF_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, tmf_last_error()); return 3; } \
+    } while (0)
+
+template <typename T>
+static T* dev_copy(const std::vector<T>& h) {
+    T* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
+    if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+}
+template <typename T>
+static std::vector<T> host_copy(const T* d, size_t n) {
+    std::vector<T> h(n);
+    if (n) (void)hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost);
+    return h;
+}
+
+struct Lcg {
+    uint64_t s;
+    uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); }
+    float unit() { return (next() & 0xffffff) / 16777216.0f; }
+};
+
+// fresh Keras-Adam step in fp32, as SURVEY.md A.1 spells it out
+static float adam_fresh(float w, float g, const tmf_adam& a) {
+    const float m = g * a.one_minus_b1, v = g * g * a.one_minus_b2;
+    return w - (m * a.alpha) / (sqrtf(v) + a.eps);
+}
+
+int main() {
+    const int m = 300, n = 200, r = 24, epochs = 5, k = 5;
+    const float lr = 1e-3f;
+    const int ld = tmf_padded_ld(r);
+    if (tmf_version() < 201 || ld < r) { fprintf(stderr, "library version %d, ld %d\n", tmf_version(), ld); return 1; }
+    Lcg rng{12345};
+    std::set<std::pair<int, int>> seen;
+    std::vector<int64_t> idx;
+    std::vector<float> val;
+    while ((int)seen.size() < 3000) {
+        const int u = rng.next() % m, j = rng.next() % n;
+        if (seen.insert({u, j}).second) { idx.push_back(u); idx.push_back(j); val.push_back(1.f + rng.next() % 5); }
+    }
+    const int64_t nnz = (int64_t)val.size();   // in insertion (i.e. arbitrary) order: tmf_csr_build sorts
+    std::vector<float> U((size_t)m * ld, 0.f), V((size_t)n * ld, 0.f);
+    for (int i = 0; i < m; ++i) for (int c = 0; c < r; ++c) U[(size_t)i * ld + c] = 0.3f * (rng.unit() - 0.5f);
+    for (int i = 0; i < n; ++i) for (int c = 0; c < r; ++c) V[(size_t)i * ld + c] = 0.3f * (rng.unit() - 0.5f);
+
+    // ---- index structures on the device ----
+    int64_t *d_idx = dev_copy(idx), *d_rowptr_u, *d_rowptr_i, *d_perm;
+    float *d_val = dev_copy(val), *d_val_u;
+    int32_t *d_col_u, *d_user_of;
+    HIP_OK(hipMalloc(&d_rowptr_u, (m + 1) * 8)); HIP_OK(hipMalloc(&d_rowptr_i, (n + 1) * 8)); HIP_OK(hipMalloc(&d_perm, nnz * 8));
+    HIP_OK(hipMalloc(&d_val_u, nnz * 4)); HIP_OK(hipMalloc(&d_col_u, nnz * 4)); HIP_OK(hipMalloc(&d_user_of, nnz * 4));
+    size_t ws_bytes = std::max(tmf_csr_build_workspace_bytes(nnz), tmf_stable_order_workspace_bytes(nnz));
+    void* d_ws;
+    HIP_OK(hipMalloc(&d_ws, ws_bytes));
+    TMF_OK_(tmf_csr_build(d_idx, d_val, nnz, m, n, d_rowptr_u, d_col_u, d_val_u, d_user_of, d_ws, ws_bytes, nullptr));
+    TMF_OK_(tmf_csc_perm(d_col_u, nnz, n, d_rowptr_i, d_perm, d_ws, ws_bytes, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    const auto rowptr_u = host_copy(d_rowptr_u, m + 1), rowptr_i = host_copy(d_rowptr_i, n + 1), perm = host_copy(d_perm, nnz);
+    const auto col_u = host_copy(d_col_u, nnz), user_of = host_copy(d_user_of, nnz);
+    const auto val_u = host_copy(d_val_u, nnz);
+    int bad = 0;
+    for (int u = 0; u < m; ++u)     // CSR: users ascending, items ascending inside a user, every pair present
+        for (int64_t q = rowptr_u[u]; q < rowptr_u[u + 1]; ++q) {
+            bad += user_of[q] != u || !seen.count({u, col_u[q]});
+            bad += q > rowptr_u[u] && col_u[q - 1] >= col_u[q];
+        }
+    bad += rowptr_u[m] != nnz || rowptr_i[n] != nnz;
+    std::vector<int32_t> row_i(nnz);
+    std::vector<float> val_i(nnz);
+    for (int64_t q = 0; q < nnz; ++q) { row_i[q] = user_of[perm[q]]; val_i[q] = val_u[perm[q]]; }
+    for (int j = 0; j < n; ++j)
+        for (int64_t q = rowptr_i[j]; q < rowptr_i[j + 1]; ++q) bad += col_u[perm[q]] != j;
+    if (bad) { fprintf(stderr, "FAIL index structures: %d violations\n", bad); return 10; }
+    int32_t *d_row_i = dev_copy(row_i);
+    float* d_val_i = dev_copy(val_i);
+
+    // one segment per row (every row is shorter than the chunk): the epilogue runs inside the pass
+    auto segments = [&](int rows, const int64_t* d_rowptr, tmf_segments& s) -> int {
+        std::vector<int32_t> iota(rows), zero(rows, 0), none(rows, -1);
+        std::iota(iota.begin(), iota.end(), 0);
+        s = tmf_segments{d_rowptr, dev_copy(iota), dev_copy(zero), dev_copy(none), rows, 1024, 0};
+        return s.seg_row && s.seg_chunk && s.seg_slab ? 0 : 1;
+    };
+    tmf_segments seg_u, seg_i;
+    if (segments(m, d_rowptr_u, seg_u) || segments(n, d_rowptr_i, seg_i)) return 2;
+
+    float *d_U = dev_copy(U), *d_V = dev_copy(V), *d_Un, *d_Vn, *d_slab, *d_lp;
+    double* d_loss;
+    HIP_OK(hipMalloc(&d_Un, U.size() * 4)); HIP_OK(hipMalloc(&d_Vn, V.size() * 4)); HIP_OK(hipMalloc(&d_slab, (size_t)ld * 4));
+    HIP_OK(hipMalloc(&d_lp, m * 4)); HIP_OK(hipMalloc(&d_loss, 8));
+    HIP_OK(hipMemset(d_Un, 0, U.size() * 4)); HIP_OK(hipMemset(d_Vn, 0, V.size() * 4));
+    const tmf_adam adam = tmf_adam_fresh(lr);
+
+    // ---- epochs: GPU through the ABI, fp64 restatement next to it ----
+    std::vector<double> Ur(U.begin(), U.end()), Vr(V.begin(), V.end());
+    double worst_loss = 0, worst_step = 0;
+    for (int ep = 0; ep < epochs; ++ep) {
+        TMF_OK_(tmf_mse_pass_f32(&seg_u, d_col_u, d_val_u, d_U, d_V, d_Un, d_slab, d_lp, r, TMF_EPI_ADAM, adam, nullptr));
+        TMF_OK_(tmf_mse_pass_f32(&seg_i, d_row_i, d_val_i, d_V, d_U, d_Vn, d_slab, nullptr, r, TMF_EPI_ADAM, adam, nullptr));
+        TMF_OK_(tmf_sum_f32(d_lp, m, d_loss, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        double loss_gpu;
+        HIP_OK(hipMemcpy(&loss_gpu, d_loss, 8, hipMemcpyDeviceToHost));
+        // reference: delta_k = -2 (a_k - p_k), gU[u] += delta_k V[j], gV[j] += delta_k U[u], all from the pre-update tables
+        std::vector<double> gU((size_t)m * r, 0.0), gV((size_t)n * r, 0.0);
+        double loss_ref = 0;
+        for (int64_t q = 0; q < nnz; ++q) {
+            const int u = user_of[q], j = col_u[q];
+            double p = 0;
+            for (int c = 0; c < r; ++c) p += Ur[(size_t)u * ld + c] * Vr[(size_t)j * ld + c];
+            const double e = val_u[q] - p, d = -2 * e;
+            loss_ref += e * e;
+            for (int c = 0; c < r; ++c) { gU[(size_t)u * r + c] += d * Vr[(size_t)j * ld + c]; gV[(size_t)j * r + c] += d * Ur[(size_t)u * ld + c]; }
+        }
+        worst_loss = std::max(worst_loss, fabs(loss_gpu - loss_ref) / loss_ref);
+        const auto Un = host_copy(d_Un, U.size()), Vn = host_copy(d_Vn, V.size());
+        auto check = [&](const std::vector<float>& Wn, std::vector<double>& Wr, const std::vector<double>& g, int rows) {
+            double gmax = 0;
+            for (double x : g) gmax = std::max(gmax, fabs(x));
+            for (int i = 0; i < rows; ++i)
+                for (int c = 0; c < r; ++c) {
+                    const double gi = g[(size_t)i * r + c];
+                    const float want = adam_fresh((float)Wr[(size_t)i * ld + c], (float)gi, adam);
+                    // the step is a near-sign function of g: compare only where g is well away from 0, then continue from the
+                    // GPU's value so that the two trajectories stay on the same tables
+                    if (fabs(gi) > 1e-3 * gmax) worst_step = std::max(worst_step, (double)fabsf(Wn[(size_t)i * ld + c] - want));
+                    Wr[(size_t)i * ld + c] = Wn[(size_t)i * ld + c];
+                }
+        };
+        check(Un, Ur, gU, m);
+        check(Vn, Vr, gV, n);
+        std::swap(d_U, d_Un);
+        std::swap(d_V, d_Vn);
+    }
+    printf("epochs %d: worst relative loss error %.3g, worst table error after a step %.3g\n", epochs, worst_loss, worst_step);
+    if (!(worst_loss < 1e-5) || !(worst_step < 2e-6)) { fprintf(stderr, "FAIL training parity\n"); return 11; }
+
+    // ---- fused predict + top-k over the catalog ----
+    int32_t* d_top;
+    float* d_topv;
+    HIP_OK(hipMalloc(&d_top, (size_t)m * k * 4)); HIP_OK(hipMalloc(&d_topv, (size_t)m * k * 4));
+    TMF_OK_(tmf_predict_topk_f32(d_U, d_V, m, n, r, ld, ld, k, 0, d_top, d_topv, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    const auto top = host_copy(d_top, (size_t)m * k);
+    const auto topv = host_copy(d_topv, (size_t)m * k);
+    int wrong = 0;
+    for (int u = 0; u < m; ++u) {
+        std::vector<double> sc(n);
+        for (int j = 0; j < n; ++j) { double p = 0; for (int c = 0; c < r; ++c) p += Ur[(size_t)u * ld + c] * Vr[(size_t)j * ld + c]; sc[j] = p; }
+        std::vector<char> taken(n, 0);
+        for (int t = 0; t < k; ++t) {
+            const int j = top[(size_t)u * k + t];
+            wrong += j < 0 || j >= n || taken[j] || fabs(topv[(size_t)u * k + t] - sc[j]) > 1e-5;
+            if (j >= 0 && j < n) taken[j] = 1;
+            wrong += t > 0 && topv[(size_t)u * k + t] > topv[(size_t)u * k + t - 1];       // descending
+        }
+        const double kth = topv[(size_t)u * k + k - 1];
+        for (int j = 0; j < n; ++j) wrong += !taken[j] && sc[j] > kth + 1e-5;              // nothing better was left out
+    }
+    printf("top-%d of %d users over %d items: %d violations\n", k, m, n, wrong);
+    if (wrong) { fprintf(stderr, "FAIL top-k\n"); return 12; }
+
+    // ---- error path: a null table is an argument error with a message, not a crash ----
+    const int rc = tmf_mse_pass_f32(&seg_u, d_col_u, d_val_u, nullptr, d_V, d_Un, d_slab, d_lp, r, TMF_EPI_ADAM, adam, nullptr);
+    if (rc == TMF_OK || !tmf_last_error()[0]) { fprintf(stderr, "FAIL error reporting\n"); return 13; }
+    printf("PASS (argument error reported as %d: %s)\n", rc, tmf_last_error());
+    return 0;
+}
