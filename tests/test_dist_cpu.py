@@ -92,10 +92,9 @@ def _worker(rank, world, port, loss, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
-def test_data_parallel_epoch_matches_single_process(loss):
-    world = 2
-    port = 29600 + (os.getpid() % 200) + (0 if loss == 'mse' else 1)
+@pytest.mark.parametrize('loss,world', [('mse', 2), ('wmrb', 2), ('wmrb', 3)])
+def test_data_parallel_epoch_matches_single_process(loss, world):
+    port = 29600 + (os.getpid() % 200) + (0 if loss == 'mse' else 1) + 2 * world
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, loss, out), nprocs=world, join=True)
@@ -242,10 +241,9 @@ def _sharded_worker(rank, world, port, loss, q, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('loss,q', [('mse', 1), ('wmrb', 1), ('mse', 3), ('wmrb', 2)])
-def test_item_sharded_epoch_matches_single_process(loss, q):
-    world = 2
-    port = 29850 + (os.getpid() % 100) + 2 * q + (0 if loss == 'mse' else 1)
+@pytest.mark.parametrize('loss,q,world', [('mse', 1, 2), ('wmrb', 1, 2), ('mse', 3, 2), ('wmrb', 2, 2), ('wmrb', 2, 3), ('mse', 1, 4)])
+def test_item_sharded_epoch_matches_single_process(loss, q, world):
+    port = 29850 + (os.getpid() % 100) + 2 * q + (0 if loss == 'mse' else 1) + 10 * world
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_sharded_worker, args=(world, port, loss, q, out), nprocs=world, join=True)
