@@ -158,10 +158,10 @@ def test_window_outside_the_resident_rows_is_never_read(tm, monkeypatch):
     assert torch.isfinite(be.part[:m]).all()
 
 
-@pytest.mark.parametrize('loss,q', [('mse', 1), ('wmrb', 1), ('wmrb', 2)])
-def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
-    """Two ranks on cuda:0 (gloo group, host-staged collectives - tools/dp_rehearsal.py with q windows per rank): each owns
-    half of every catalog window, the windows are assembled by all-gather one at a time, and the per-window reduce-scatter
+@pytest.mark.parametrize('loss,q,world', [('mse', 1, 2), ('wmrb', 1, 2), ('wmrb', 2, 2), ('wmrb', 1, 4)])
+def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q, world):
+    """Two (or four) ranks on cuda:0 (gloo group, host-staged collectives - tools/dp_rehearsal.py with q windows per rank): each
+    owns its share of every catalog window, the windows are assembled by all-gather one at a time, and the per-window reduce-scatter
     hands every owner the summed gradient of its rows.  Against the single-process resident fit: same loss trajectory, tables equal except
     where a gradient element is ~0 (different summation order)."""
     with socket.socket() as sk:
@@ -169,15 +169,15 @@ def test_two_ranks_item_sharded_on_one_card(tmp_path, loss, q):
         port = sk.getsockname()[1]
     out = tmp_path / 'shard.json'
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'dp_rehearsal.py'), str(out), loss, str(q)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
     res = json.loads(out.read_text())
-    (b0, e0), (b1, e1) = res['blocks']
-    assert b0 == 0 and e0 == b1 and e1 == 3001 and 0 < e0 < 3001
+    blocks = res['blocks']
+    assert blocks[0][0] == 0 and blocks[-1][1] == 3001 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:])) and all(b0 < b1 for b0, b1 in blocks)
     assert res['item_rows_partition_the_catalog'] and all(0 < c < 701 for c in res['item_rows_per_rank'])   # split, nobody owns all
     assert abs(res['loss_dp'][0] - res['loss_one'][0]) <= 1e-6 * abs(res['loss_one'][0])
     assert rel_err(res['loss_dp'], res['loss_one']) < 1e-5
