@@ -1,5 +1,6 @@
 // A compiled caller of the C ABI (include/tmf.h) with no Python and no torch in the process: builds the index
-// structures, runs MSE epochs (matrix_factorization.py:130-176 with MSELoss) and a fused predict + top-k on the GPU
+// structures, runs MSE epochs (matrix_factorization.py:130-176 with MSELoss), a fused predict + top-k and WMRB epochs
+// (the sliced scores / hinge / gradU / finish kernels and the item-side gather-sum) on the GPU
 // through libtmf.so, and checks the results against a plain fp64 restatement kept in this file (test infrastructure).
 // Built by tests/cabi/Makefile (hipcc; only the HIP runtime API is used on the host side), run by
 // tests/test_gpu_cabi.py.  Exit code 0 = every check passed.
@@ -188,6 +189,110 @@ int main() {
     }
     printf("top-%d of %d users over %d items: %d violations\n", k, m, n, wrong);
     if (wrong) { fprintf(stderr, "FAIL top-k\n"); return 12; }
+
+    // ---- WMRB epochs through the sliced kernels (loss_graphs.py:74-88), static negative table R ----
+    {
+        const int S = 16, ns = 3, C = 2, wepochs = 3;
+        const float wlr = 1e-3f, cc = (float)n / (float)S;
+        std::vector<int32_t> R((size_t)m * S);
+        for (int u = 0; u < m; ++u) {       // S distinct items per user (utils.py:20 draws without replacement)
+            std::set<int> pick;
+            while ((int)pick.size() < S) pick.insert(rng.next() % n);
+            int t = 0;
+            std::vector<int> v(pick.begin(), pick.end());
+            for (int q = S - 1; q > 0; --q) std::swap(v[q], v[rng.next() % (q + 1)]);     // any order: the engine sorts its copy
+            for (int j : v) R[(size_t)u * S + t++] = j;
+        }
+        int32_t *d_R = dev_copy(R), *d_Rs, *d_off, *d_poff, *d_ent_row, *d_ent_id;
+        int64_t* d_rowptr_e;
+        const int64_t E = nnz + (int64_t)m * S;
+        HIP_OK(hipMalloc(&d_Rs, R.size() * 4)); HIP_OK(hipMalloc(&d_off, (size_t)m * (ns + 1) * 4)); HIP_OK(hipMalloc(&d_poff, (size_t)m * (ns + 1) * 4));
+        HIP_OK(hipMalloc(&d_ent_row, E * 4)); HIP_OK(hipMalloc(&d_ent_id, E * 4)); HIP_OK(hipMalloc(&d_rowptr_e, ((size_t)C * n + 2) * 8));
+        const size_t wsb = std::max(tmf_sort_samples_workspace_bytes(m, S), tmf_wmrb_entry_lists_workspace_bytes(nnz, m, S));
+        void* d_ws2;
+        HIP_OK(hipMalloc(&d_ws2, wsb));
+        TMF_OK_(tmf_sort_samples(d_R, m, S, n, d_Rs, d_ws2, wsb, nullptr));
+        TMF_OK_(tmf_slice_offsets(d_Rs, nullptr, S, m, n, ns, d_off, nullptr));
+        TMF_OK_(tmf_slice_offsets(d_col_u, d_rowptr_u, 0, m, n, ns, d_poff, nullptr));
+        TMF_OK_(tmf_wmrb_entry_lists(d_user_of, d_col_u, d_val_u, nnz, d_Rs, m, S, n, C, d_ent_row, d_ent_id, d_rowptr_e, d_ws2, wsb, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        const auto Rs = host_copy(d_Rs, R.size());
+        // lists: one segment per (user block, item) list, every one with a slab slot, slots item-major (tmf_combine_rows sums them)
+        std::vector<int32_t> seg_row(C * n), seg_chunk(C * n, 0), seg_slab(C * n), items(n);
+        std::vector<int64_t> slab_beg(n + 1);
+        for (int c = 0; c < C; ++c) for (int j = 0; j < n; ++j) { seg_row[c * n + j] = c * n + j; seg_slab[c * n + j] = j * C + c; }
+        for (int j = 0; j <= n; ++j) slab_beg[j] = (int64_t)j * C;
+        std::iota(items.begin(), items.end(), 0);
+        tmf_segments seg_e{d_rowptr_e, dev_copy(seg_row), dev_copy(seg_chunk), dev_copy(seg_slab), (int64_t)C * n, 1024, 0};
+        int32_t* d_items = dev_copy(items);
+        int64_t* d_slab_beg = dev_copy(slab_beg);
+        tmf_slice_lists lists{d_Rs, d_off, d_rowptr_u, d_col_u, d_poff, m, S, ns, 0, 0, 0};
+        float *d_sp, *d_pk, *d_wbuf, *d_part, *d_slab2, *d_lp2;
+        HIP_OK(hipMalloc(&d_sp, (size_t)m * S * 4)); HIP_OK(hipMalloc(&d_pk, nnz * 4)); HIP_OK(hipMalloc(&d_wbuf, E * 4));
+        HIP_OK(hipMalloc(&d_part, (size_t)ns * m * ld * 4)); HIP_OK(hipMalloc(&d_slab2, (size_t)C * n * ld * 4)); HIP_OK(hipMalloc(&d_lp2, m * 4));
+        float *d_delta = d_wbuf, *d_D = d_wbuf + nnz;
+        HIP_OK(hipMemcpy(d_U, U.data(), U.size() * 4, hipMemcpyHostToDevice));     // start again from the initial tables
+        HIP_OK(hipMemcpy(d_V, V.data(), V.size() * 4, hipMemcpyHostToDevice));
+        std::vector<double> Uw(U.begin(), U.end()), Vw(V.begin(), V.end());
+        const tmf_adam wadam = tmf_adam_fresh(wlr);
+        double wl = 0, wst = 0;
+        for (int ep = 0; ep < wepochs; ++ep) {
+            TMF_OK_(tmf_wmrb_scores3_f32(&lists, d_U, d_V, d_sp, d_pk, r, nullptr));
+            TMF_OK_(tmf_wmrb_hinge2(d_rowptr_u, d_val_u, d_pk, d_sp, m, S, cc, d_delta, d_D, d_lp2, nullptr));
+            TMF_OK_(tmf_wmrb_gradu3_f32(&lists, d_D, d_delta, d_V, d_part, 0, r, nullptr));
+            TMF_OK_(tmf_wmrb_finish_f32(d_part, ns, m, d_U, d_Un, r, TMF_EPI_ADAM, wadam, nullptr));
+            TMF_OK_(tmf_sum_f32(d_lp2, m, d_loss, nullptr));
+            TMF_OK_(tmf_wsum_pass_f32(&seg_e, d_ent_row, d_ent_id, d_wbuf, d_U, d_V, d_Vn, d_slab2, r, TMF_EPI_ADAM, wadam, nullptr));
+            TMF_OK_(tmf_combine_rows_f32(d_items, d_slab_beg, n, d_slab2, d_V, d_Vn, r, TMF_EPI_ADAM, wadam, nullptr));
+            HIP_OK(hipDeviceSynchronize());
+            double loss_gpu;
+            HIP_OK(hipMemcpy(&loss_gpu, d_loss, 8, hipMemcpyDeviceToHost));
+            // reference (every stored value is > 0 here, so every interaction is a positive)
+            std::vector<double> gU((size_t)m * r, 0.0), gV((size_t)n * r, 0.0);
+            double loss_ref = 0;
+            for (int u = 0; u < m; ++u) {
+                std::vector<double> sps(S), Dd(S, 0.0);
+                for (int t = 0; t < S; ++t) { double p = 0; const int j = Rs[(size_t)u * S + t]; for (int c = 0; c < r; ++c) p += Uw[(size_t)u * ld + c] * Vw[(size_t)j * ld + c]; sps[t] = p; }
+                for (int64_t q = rowptr_u[u]; q < rowptr_u[u + 1]; ++q) {
+                    const int j = col_u[q];
+                    double p = 0;
+                    for (int c = 0; c < r; ++c) p += Uw[(size_t)u * ld + c] * Vw[(size_t)j * ld + c];
+                    double M = 0;
+                    int cnt = 0;
+                    for (int t = 0; t < S; ++t) { const double x = 1.0 - p + sps[t]; if (x >= 0) { M += x; ++cnt; } }
+                    M *= cc;
+                    loss_ref += log1p(M);
+                    const double w = cc / (1.0 + M), dk = -w * cnt;
+                    for (int t = 0; t < S; ++t) if (1.0 - p + sps[t] >= 0) Dd[t] += w;
+                    for (int c = 0; c < r; ++c) { gU[(size_t)u * r + c] += dk * Vw[(size_t)j * ld + c]; gV[(size_t)j * r + c] += dk * Uw[(size_t)u * ld + c]; }
+                }
+                for (int t = 0; t < S; ++t) {
+                    const int j = Rs[(size_t)u * S + t];
+                    for (int c = 0; c < r; ++c) { gU[(size_t)u * r + c] += Dd[t] * Vw[(size_t)j * ld + c]; gV[(size_t)j * r + c] += Dd[t] * Uw[(size_t)u * ld + c]; }
+                }
+            }
+            wl = std::max(wl, fabs(loss_gpu - loss_ref) / loss_ref);
+            const auto Un = host_copy(d_Un, U.size()), Vn = host_copy(d_Vn, V.size());
+            auto check = [&](const std::vector<float>& Wn, std::vector<double>& Wr, const std::vector<double>& g, int rows) {
+                double gmax = 0;
+                for (double x : g) gmax = std::max(gmax, fabs(x));
+                for (int i = 0; i < rows; ++i)
+                    for (int c = 0; c < r; ++c) {
+                        const double gi = g[(size_t)i * r + c];
+                        const float want = adam_fresh((float)Wr[(size_t)i * ld + c], (float)gi, wadam);
+                        if (fabs(gi) > 1e-3 * gmax) wst = std::max(wst, (double)fabsf(Wn[(size_t)i * ld + c] - want));
+                        Wr[(size_t)i * ld + c] = Wn[(size_t)i * ld + c];
+                    }
+            };
+            check(Un, Uw, gU, m);
+            check(Vn, Vw, gV, n);
+            std::swap(d_U, d_Un);
+            std::swap(d_V, d_Vn);
+        }
+        printf("WMRB (S=%d, %d slices, %d user blocks) %d epochs: worst relative loss error %.3g, worst table error after a step %.3g\n", S,
+               ns, C, wepochs, wl, wst);
+        if (!(wl < 1e-5) || !(wst < 2e-6)) { fprintf(stderr, "FAIL WMRB parity\n"); return 14; }
+    }
 
     // ---- error path: a null table is an argument error with a message, not a crash ----
     const int rc = tmf_mse_pass_f32(&seg_u, d_col_u, d_val_u, nullptr, d_V, d_Un, d_slab, d_lp, r, TMF_EPI_ADAM, adam, nullptr);

@@ -1,6 +1,6 @@
 """The C ABI used by a compiled caller (tests/cabi/cabi_fit.cpp): no Python and no torch in that process - hipMalloc'd buffers,
-tmf_csr_build / tmf_csc_perm, MSE epochs through tmf_mse_pass_f32, the loss through tmf_sum_f32, fused predict + top-k, and the
-error path, each checked inside the program against its own fp64 restatement."""
+tmf_csr_build / tmf_csc_perm, MSE epochs through tmf_mse_pass_f32, the loss through tmf_sum_f32, fused predict + top-k, WMRB
+epochs through the sliced kernels and the item-side gather-sum, and the error path, each checked inside the program against its own fp64 restatement."""
 import os
 import subprocess
 
