@@ -5,6 +5,7 @@ import importlib.util
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN, assert_step, rel_err
@@ -228,3 +229,51 @@ def test_boundary_slack_c_equals_numpy_and_is_zero_away_from_the_kink(golden):
             assert b['pairs'] > 20 and b['pairs'] < 0.2 * pos.sum() * S_
             assert rel_err(a['D'], b['D']) < 0.1 and rel_err(a['gU'], b['gU']) < 0.1 and rel_err(a['gV'], b['gV']) < 0.1
             assert rel_err(a['delta'][pos], b['delta']) < 0.1
+
+
+def _loss_sum_by_definition(U, V, idx, val, loss, R=None, n_items=None, n_samples=None):
+    """Sum of the per-interaction losses written out from the definitions (loss_graphs.py:47-52 / :74-88) with plain loops -
+    no closed-form gradient, no vectorised helper of the oracle involved."""
+    import math
+    total = 0.0
+    for (u, j), a in zip(idx.tolist(), val.tolist()):
+        p = float(np.dot(U[u], V[j]))
+        if loss == 'mse':
+            total += (a - p) ** 2
+        elif a > 0:
+            hinge = sum(max(0.0, 1.0 - p + float(np.dot(U[u], V[s]))) for s in R[u].tolist())
+            total += math.log(1.0 + (n_items / n_samples) * hinge)
+    return total
+
+
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+def test_closed_form_gradients_match_finite_differences(loss):
+    """A line of evidence that does not pass through autograd or through the hand derivation: central differences of the loss
+    written out from its definition against the closed-form gradients the sparse oracle (and with it every kernel test) uses.
+    What `tape.gradient` differentiates is the SUM of the per-interaction losses (matrix_factorization.py:170-171)."""
+    rng = np.random.default_rng(5)
+    m, n, r, Sn = 9, 11, 4, 5
+    A = (rng.random((m, n)) < 0.4) * rng.integers(1, 6, (m, n))
+    idx = np.argwhere(A != 0)
+    val = A[A != 0].astype(np.float64)
+    val[::5] = -1.0 if loss == 'mse' else 0.0          # MSE fits negative values too; WMRB skips stored non-positives
+    U = rng.standard_normal((m, r)) * 0.4
+    V = rng.standard_normal((n, r)) * 0.4
+    R = np.stack([rng.choice(n, Sn, replace=False) for _ in range(m)])
+    if loss == 'mse':
+        t = S.mse_epoch(U, V, idx, val, 0.01)[3]
+    else:
+        t = S.wmrb_epoch(U, V, idx, val, R, n, Sn, 0.01)[3]
+        x = 1.0 - t['p'][:, None] + t['sp'][idx[t['pos'], 0]]
+        assert np.abs(x).min() > 1e-4                   # no hinge argument near the kink: the loss is smooth around (U, V)
+    h = 1e-6
+    for W, g, name in ((U, t['gU'], 'U'), (V, t['gV'], 'V')):
+        for i, c in zip(rng.integers(0, W.shape[0], 12), rng.integers(0, r, 12)):
+            keep = W[i, c]
+            W[i, c] = keep + h
+            up = _loss_sum_by_definition(U, V, idx, val, loss, R, n, Sn)
+            W[i, c] = keep - h
+            dn = _loss_sum_by_definition(U, V, idx, val, loss, R, n, Sn)
+            W[i, c] = keep
+            fd = (up - dn) / (2 * h)
+            assert abs(fd - g[i, c]) <= 1e-6 * max(1.0, np.abs(g).max()), (name, i, c, fd, g[i, c])
