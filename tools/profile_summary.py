@@ -7,6 +7,20 @@ import json
 import os
 import sys
 
+import shutil
+import subprocess
+
+
+def demangle(name, _cache={}):
+    if name not in _cache:
+        tool = shutil.which('llvm-cxxfilt') or '/opt/rocm/lib/llvm/bin/llvm-cxxfilt'
+        try:
+            _cache[name] = subprocess.run([tool, name], stdout=subprocess.PIPE, check=True).stdout.decode().strip()
+        except Exception:
+            _cache[name] = name.replace('_ZN3tmf', 'tmf::')
+    return _cache[name]
+
+
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(src, 'summary')
@@ -22,8 +36,11 @@ out = {}
 for kind, cn in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     agg, meta = collections.defaultdict(list), {}
     for r in csv.DictReader(open(glob.glob(f'{src}/{kind}/*/*_counter_collection.csv')[0])):
-        if 'tmf::' in r['Kernel_Name']:
-            k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        name = r['Kernel_Name']
+        if name.startswith('_ZN3tmf'):   # bf16 instantiations come out mangled (the _BFloat16 template argument)
+            name = demangle(name)
+        if 'tmf::' in name:
+            k = name.split('(')[0].replace('void ', '')
             agg[k].append(float(r['Counter_Value']))
             meta[k] = dict(vgpr=r['VGPR_Count'], agpr=r['Accum_VGPR_Count'], sgpr=r['SGPR_Count'], lds=r['LDS_Block_Size'],
                            workgroup=r['Workgroup_Size'], grid=r['Grid_Size'])
