@@ -366,8 +366,9 @@ class Workload:
         self.wplan, self.R = None, None
         if loss == 'wmrb':
             self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
+            ns, sliced = _engine.choose_wmrb_user_pass(m, n, ld, S, self.plan.n_pos, r)
             self.wplan = _engine.WmrbPlan(self.plan, self.R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n),
-                                          item_slices=_engine.default_item_slices(n, ld), n_components=r)
+                                          item_slices=ns, n_components=r, sliced=sliced)
         self.st = _engine.TrainState(U0, V0, self.plan, r, self.wplan, dtype=torch.bfloat16 if dtype == 'bf16' else torch.float32)
         self.adam = _engine.adam_constants(args.lr)
         self.c = n / S

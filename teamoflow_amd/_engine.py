@@ -248,6 +248,28 @@ def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20):
     return int(min(-(-n_items * ld * 4 // target_bytes), 64))
 
 
+SLICED_MIN_HINGE_TERMS = 1 << 16   # positives x negatives per user from which the O((S + P) log P) hinge step pays
+SLICED_MIN_SCORES = 1 << 21        # n_users x n_samples below which the epoch is launch-bound and one fused kernel wins
+
+
+def choose_wmrb_user_pass(n_users, n_items, ld, n_samples, n_positives, n_components):
+    """(item_slices, sliced) for a WMRB fit.  Large catalogs: the sliced pass with ~4 MB slices (default_item_slices).
+    Small catalogs (V in the L2s, scores in LDS) default to the one-kernel pass, whose hinge step costs P_u x S terms per
+    user - at the MovieLens-1M shape (C3: 6040 x 3706, S = 1853, 165 positives per user) that is 3e5 terms per user and
+    the sliced pass with its O((S + P) log P) hinge kernel is faster although the catalog needs no slicing: 0.37 ms
+    against 0.61 ms per user pass, item pass 0.20 against 0.26 (sorted negatives) - profiles/r02_hinge_rewrite.txt item 11.
+    The slice count then only provides workgroups (the kernels also shrink their user groups, tmf_wmrb.hip)."""
+    ns = default_item_slices(n_items, ld)
+    if ns > 1 or not fused_user_pass_fits(n_samples, n_components) or os.environ.get('TMF_FORCE_SLICED') == '1':
+        return ns, True
+    if os.environ.get('TMF_ITEM_SLICES') or os.environ.get('TMF_FORCE_FUSED') == '1':
+        return ns, False
+    if (n_positives / max(n_users, 1)) * n_samples >= SLICED_MIN_HINGE_TERMS and n_users * n_samples >= SLICED_MIN_SCORES:
+        groups = -(-n_users // 16)
+        return int(min(max(round(1400 / groups), 1), 8)), True
+    return 1, False
+
+
 def fused_user_pass_fits(n_samples, n_components):
     """The one-kernel user pass keeps a user's scores and D in LDS; above ~13K negatives they do not fit and the sliced
     pass (no such limit) takes over whatever the catalog size."""

@@ -48,8 +48,9 @@ def fit_minibatch(model, epochs, n_users, n_items, interactions, lr, U0, V0, bat
                                        user_chunks=1 if wmrb else _engine.mse_user_chunks(), csc=not wmrb)
         wplan = None
         if wmrb:
+            ns, sliced = _engine.choose_wmrb_user_pass(b1 - b0, n_items, ld, int(R.shape[1]), plan.n_pos, r)
             wplan = _engine.WmrbPlan(plan, R[b0:b1].contiguous(), user_chunks=_engine.default_user_chunks(b1 - b0, ld, n_items=n_items),
-                                     item_slices=_engine.default_item_slices(n_items, ld), n_components=r)
+                                     item_slices=ns, n_components=r, sliced=sliced)
         states.append(_engine.TrainState(U0[b0:b1], None, plan, r, wplan, dtype=dtype, V_tables=tuple(tables), scratch=scratch))
     _engine.share_scratch(scratch, dev)
     adam = _engine.adam_constants(lr)

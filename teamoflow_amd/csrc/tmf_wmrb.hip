@@ -370,7 +370,7 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 // (An in-launch variant - scores + hinge in one launch behind an agent-scope ticket - was measured slower and
 // removed; see profiles/r01_sliced_user_pass.txt.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kSliceUsers = 128;  // users per workgroup
+constexpr int kSliceUsers = 128;  // users per workgroup (fewer when that would leave CUs without a workgroup: SliceLists::upg)
 
 template <int G>
 struct Stage {
@@ -445,6 +445,7 @@ struct SliceLists {
     const int32_t* poff;     // [n_users, n_slices + 1] first interaction of every slice, relative to rowptr[u]
     int n_slices, S;
     int64_t n_users, n_groups;
+    int upg;                 // users per workgroup
     int sl0, nsl;            // slices [sl0, sl0 + nsl) are covered by this launch ...
     int item_base;           // ... and V points at item row item_base (windowed V: only these rows are resident)
 };
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T
     int* ids = slice_stage<G>(smem_raw, gid);
     float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
     const int64_t sl = a.sl0 + blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
-    const int64_t ubeg = grp * kSliceUsers;
-    const int64_t uend = (ubeg + kSliceUsers < a.n_users) ? ubeg + kSliceUsers : a.n_users;
+    const int64_t ubeg = grp * a.upg;
+    const int64_t uend = (ubeg + a.upg < a.n_users) ? ubeg + a.upg : a.n_users;
     V = window_base<G, NV, T>(V, a.item_base);
     for (int64_t u = ubeg + gid; u < uend; u += NGB) {
         const int64_t o = u * (a.n_slices + 1) + sl;
@@ -496,8 +497,8 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_gradu3(SliceLists a, const T*
     float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
     const int64_t sl = (slice_first >= 0) ? slice_first : a.sl0 + blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
     V = window_base<G, NV, T>(V, a.item_base);
-    const int64_t ubeg = grp * kSliceUsers;
-    const int64_t uend = (ubeg + kSliceUsers < a.n_users) ? ubeg + kSliceUsers : a.n_users;
+    const int64_t ubeg = grp * a.upg;
+    const int64_t uend = (ubeg + a.upg < a.n_users) ? ubeg + a.upg : a.n_users;
     for (int64_t u = ubeg + gid; u < uend; u += NGB) {
         const int64_t o = u * (a.n_slices + 1) + sl;
         const int nb = a.off[o], ne = a.off[o + 1], pb = a.poff[o], pe = a.poff[o + 1];
@@ -588,13 +589,17 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
     TMF_REQUIRE(l->n_users >= 0 && l->n_slices > 0 && l->n_samples > 0, "%s: n_users=%d n_slices=%d n_samples=%d", what,
                 l->n_users, l->n_slices, l->n_samples);
     TMF_REQUIRE(l->n_users == 0 || (l->R_sorted && l->slice_off && l->rowptr && l->pos_off), "%s: null list array", what);
-    const int64_t groups = ((int64_t)l->n_users + kSliceUsers - 1) / kSliceUsers;
+    // users per workgroup: 128, halved while the launch would have fewer than ~4 workgroups per CU (small user counts: the
+    // MovieLens shapes), never below the 16 lane groups a workgroup can have (one user per lane group and step)
+    int upg = kSliceUsers;
+    while (upg > 16 && (((int64_t)l->n_users + upg - 1) / upg) * l->n_slices < 1024) upg >>= 1;
+    const int64_t groups = ((int64_t)l->n_users + upg - 1) / upg;
     TMF_REQUIRE(groups * l->n_slices < ((int64_t)1 << 31), "%s: grid too large", what);
     const int sl0 = l->slice_begin, nsl = l->slice_count > 0 ? l->slice_count : l->n_slices - sl0;
     TMF_REQUIRE(sl0 >= 0 && nsl > 0 && sl0 + nsl <= l->n_slices && l->item_base >= 0, "%s: window [%d, +%d) of %d slices, item_base=%d",
                 what, sl0, l->slice_count, l->n_slices, l->item_base);
     a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups,
-                   sl0, nsl, l->item_base};
+                   upg, sl0, nsl, l->item_base};
     return TMF_OK;
 }
 

@@ -171,9 +171,10 @@ class MatrixFactorization:
             if R.numel() and (int(R.min()) < 0 or int(R.max()) >= n_items):
                 raise IndexError('random_ind holds item ids outside [0, n_items)')
             c = self.n_items / self.n_samples  # constructor ints, true division (:167)
+            ns, sliced = _engine.choose_wmrb_user_pass(n_users, n_items, _lib.padded_ld(self.n_components), int(R.shape[1]), plan.n_pos,
+                                                       self.n_components)
             wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(n_users, _lib.padded_ld(self.n_components), n_items=n_items),
-                                      item_slices=_engine.default_item_slices(n_items, _lib.padded_ld(self.n_components)),
-                                      n_components=self.n_components)
+                                     item_slices=ns, n_components=self.n_components, sliced=sliced)
         st = _engine.TrainState(U0, V0, plan, self.n_components, wplan, dtype=self.factor_dtype)
         adam = _engine.adam_constants(lr)
         loss_sums = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)

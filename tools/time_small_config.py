@@ -19,8 +19,8 @@ plan = _engine.InteractionPlan(idx, val, m, n)
 wplan = None
 if loss == 'wmrb':
     R = random_sampler_device(n, m, S, seed=1, device=dev)
-    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n),
-                             item_slices=_engine.default_item_slices(n, ld))
+    ns, sliced = _engine.choose_wmrb_user_pass(m, n, ld, S, plan.n_pos, r)
+    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n), item_slices=ns, n_components=r, sliced=sliced)
 U0 = torch.rand(m, r, device=dev) * 0.01
 V0 = torch.rand(n, r, device=dev) * 0.01
 st = _engine.TrainState(U0, V0, plan, r, wplan)
