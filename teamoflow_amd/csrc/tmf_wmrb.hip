@@ -8,6 +8,7 @@
 //   phase 3  gU += sum_s D[s] V[R[u,s]], D -> global, gU -> epilogue (fresh Adam or raw gradient)
 // The [P, S] hinge tensor of loss_graphs.py:80-84 is never materialised.
 #include <math.h>
+#include <stdlib.h>
 
 #include "tmf_common.h"
 
@@ -370,7 +371,7 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 // (An in-launch variant - scores + hinge in one launch behind an agent-scope ticket - was measured slower and
 // removed; see profiles/r01_sliced_user_pass.txt.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kSliceUsers = 128;  // users per workgroup (fewer when that would leave CUs without a workgroup: SliceLists::upg)
+constexpr int kSliceUsers = 16;   // users per workgroup of the slice kernels (SliceLists::upg)
 
 template <int G>
 struct Stage {
@@ -584,15 +585,20 @@ extern "C" int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col
 }
 
 // ---- sliced pass: storage-type generic implementations + the _f32 / _bf16 entry points ----
-static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what) {
+static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what, int lanes_per_row) {
     TMF_REQUIRE(l != nullptr, "%s: lists is null", what);
     TMF_REQUIRE(l->n_users >= 0 && l->n_slices > 0 && l->n_samples > 0, "%s: n_users=%d n_slices=%d n_samples=%d", what,
                 l->n_users, l->n_slices, l->n_samples);
     TMF_REQUIRE(l->n_users == 0 || (l->R_sorted && l->slice_off && l->rowptr && l->pos_off), "%s: null list array", what);
-    // users per workgroup: 128, halved while the launch would have fewer than ~4 workgroups per CU (small user counts: the
-    // MovieLens shapes), never below the 16 lane groups a workgroup can have (one user per lane group and step)
-    int upg = kSliceUsers;
-    while (upg > 16 && (((int64_t)l->n_users + upg - 1) / upg) * l->n_slices < 1024) upg >>= 1;
+    // users per workgroup: 16 (one or two per lane group).  Small groups balance skewed users and leave no tail: against 128
+    // per workgroup, same box - C4 99.2 vs 100.4 ms, config-5 shard 249.6 vs 254.7, 200K x 50K r=64 6.99 vs 7.40,
+    // 20K x 200K r=128 2.61 vs 3.59, MovieLens-1M shape user pass 0.37 vs 1.07 ms.  TMF_SLICE_USERS overrides (A/B runs).
+    const int lane_groups = (64 / (lanes_per_row > 0 ? lanes_per_row : 64)) * kWaves;   // narrow rows: many lane groups per workgroup
+    int upg = kSliceUsers > lane_groups ? kSliceUsers : lane_groups;                    // at least one user for each of them
+    if (const char* env = getenv("TMF_SLICE_USERS")) {
+        const int v = atoi(env);
+        if (v >= 16 && v <= 1024 && (v & (v - 1)) == 0) upg = v;
+    }
     const int64_t groups = ((int64_t)l->n_users + upg - 1) / upg;
     TMF_REQUIRE(groups * l->n_slices < ((int64_t)1 << 31), "%s: grid too large", what);
     const int sl0 = l->slice_begin, nsl = l->slice_count > 0 ? l->slice_count : l->n_slices - sl0;
@@ -611,10 +617,10 @@ template <typename T>
 static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,
                              int n_components, void* stream) {
     SliceLists a;
-    if (int rc = check_lists(lists, a, "wmrb_scores3")) return rc;
+    const RowGeom geom = row_geom_of<T>(n_components);
+    if (int rc = check_lists(lists, a, "wmrb_scores3", geom.G)) return rc;
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(U && V && sp && (p || lists->col == nullptr), "wmrb_scores3: null pointer");
-    const RowGeom geom = row_geom_of<T>(n_components);
     const size_t lds = slice_lds(geom);
 #define CALL(G_, NV_)                                                                                              \
     hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(kThreads), lds, \
@@ -628,10 +634,10 @@ template <typename T>
 static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, float* part,
                             int per_slice_launches, int n_components, void* stream) {
     SliceLists a;
-    if (int rc = check_lists(lists, a, "wmrb_gradu3")) return rc;
+    const RowGeom geom = row_geom_of<T>(n_components);
+    if (int rc = check_lists(lists, a, "wmrb_gradu3", geom.G)) return rc;
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
-    const RowGeom geom = row_geom_of<T>(n_components);
     const size_t lds = slice_lds(geom);
     TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 2, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
     if (per_slice_launches) {
