@@ -266,7 +266,8 @@ def choose_wmrb_user_pass(n_users, n_items, ld, n_samples, n_positives, n_compon
         return ns, False
     if (n_positives / max(n_users, 1)) * n_samples >= SLICED_MIN_HINGE_TERMS and n_users * n_samples >= SLICED_MIN_SCORES:
         groups = -(-n_users // 16)
-        return int(min(max(round(1400 / groups), 1), 8)), True
+        # slices: enough workgroups for a small user count, and no slice larger than one XCD L2 once the pass is sliced anyway
+        return int(max(min(max(round(1400 / groups), 1), 8), -(-n_items * ld * 4 // (4 << 20)))), True
     return 1, False
 
 
