@@ -2,6 +2,7 @@
 // gather-sum used by the WMRB item side, the combine of multi-segment rows, the standalone
 // fresh-Adam row update and the deterministic loss sum.  See include/tmf.h for the contracts
 // and DESIGN.md for the bytes each kernel moves.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "tmf_common.h"
@@ -162,6 +163,68 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
     }
 }
 
+// One lane GROUP per segment instead of one wave: the 64/G groups of a wave walk 64/G different segments (two 69-entry lists
+// per wave at C4), there is no sum across groups at the end and half as many waves.  Same box, item pass: C4 fp32 34.0 ->
+// 32.6 ms, C4 bf16 27.8 -> 25.0 ms.  Used for rows of 16 lanes or more (narrower rows would leave each group a tile of
+// a few dozen staged entries); TMF_WSUM_PER_GROUP=0 selects k_wsum_pass for A/B runs.
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
+    SegView sv, const int32_t* __restrict__ ent_row, const int32_t* __restrict__ ent_w,
+    const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
+    void* __restrict__ X_out, float* __restrict__ slab, int epi, tmf_adam adam) {
+    constexpr int NG = 64 / G, TILE = kWsumTile / NG;
+    __shared__ int s_ids[kWavesPerBlock][kWsumTile];
+    __shared__ float s_w[kWavesPerBlock][kWsumTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane & (G - 1), grp = lane / G;
+    const int64_t seg = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * NG + grp;
+    const bool live = seg < sv.nseg;
+    const int row = live ? sv.seg_row[seg] : 0;
+    int64_t beg = 0, end = 0;
+    if (live) {
+        const int64_t rbeg = sv.rowptr[row], rend = sv.rowptr[row + 1];
+        beg = rbeg + (int64_t)sv.seg_chunk[seg] * sv.chunk;
+        end = (beg + sv.chunk < rend) ? beg + sv.chunk : rend;
+    }
+    int* ids = s_ids[wave] + grp * TILE;
+    float* ws = s_w[wave] + grp * TILE;
+    Frag<NV> acc;
+    zero<NV>(acc);
+    for (int64_t t0 = beg; t0 < end; t0 += TILE) {
+        const int cnt = (int)((end - t0 < TILE) ? end - t0 : TILE);
+        for (int e = g; e < cnt; e += G) {
+            ids[e] = ent_row[t0 + e];
+            ws[e] = wbuf[ent_w[t0 + e]];
+        }
+        for (int e0 = 0; e0 < cnt; e0 += kUnroll) {
+            Raw<NV, T> raw[kUnroll];
+            float wc[kUnroll];
+#pragma unroll
+            for (int t = 0; t < kUnroll; ++t) {
+                const int e = e0 + t;
+                wc[t] = (e < cnt) ? ws[e] : 0.f;
+                if constexpr (std::is_same<T, float>::value) {
+                    if (wc[t] != 0.f) load_raw<G, NV>(raw[t], Tab, ids[e], g);
+                    else zero_raw<NV>(raw[t]);
+                } else {
+                    load_raw<G, NV>(raw[t], Tab, ids[wc[t] != 0.f ? e : 0], g);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kUnroll; ++t) {
+                Frag<NV> y;
+                to_frag<NV>(y, raw[t]);
+                axpy<NV>(acc, wc[t], y);
+            }
+        }
+    }
+    if (live) {
+        const int slot = sv.seg_slab[seg];
+        if (slot < 0) row_epilogue<G, NV, T>(acc, X_old, X_out, row, g, epi, adam);
+        else store_row_f32<G, NV, T>(acc, slab, slot, g);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rows cut into several segments: sum the slab slots in slot order (group t takes slots t, t+NG..
 // then the fixed butterfly over groups), then the epilogue.
@@ -304,6 +367,22 @@ static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wsum_pass: bad epilogue %d", epi);
     const RowGeom geom = row_geom_of<T>(n_components);
     const SegView sv = view(seg);
+    {
+        const char* env = getenv("TMF_WSUM_PER_GROUP");
+        // ... and only when the segments still fill the chip at 64/G of them per wave (MovieLens-1M shape: 15K segments of
+        // 1024 entries - 245 us per group against 206 us per wave)
+        const bool forced = env && env[0] == '1';
+        if (!(env && env[0] == '0') && geom.G >= 16 && (forced || seg->nseg / (64 / geom.G) >= 16384)) {
+            const int64_t per_block = (int64_t)kWavesPerBlock * (64 / geom.G);
+            const unsigned pblocks = (unsigned)((seg->nseg + per_block - 1) / per_block);
+#define CALLPG(G_, NV_)                                                                                               \
+    hipLaunchKernelGGL((k_wsum_pass_pg<G_, NV_, T>), dim3(pblocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
+                       sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
+            TMF_DISPATCH(T, geom, CALLPG);
+#undef CALLPG
+            return check_launch("tmf_wsum_pass (per group)");
+        }
+    }
     const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
 #define CALL(G_, NV_)                                                                                           \
     hipLaunchKernelGGL((k_wsum_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
