@@ -212,6 +212,39 @@ def test_every_rank_geometry_mse_and_wmrb(tm, r):
     assert rel_err(w._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('r', [33, 64, 100, 128, 200, 256, 300, 512])
+def test_item_pass_lane_group_per_list_every_geometry(tm, monkeypatch, r, dtype):
+    """k_wsum_pass_pg (one lane group per list segment) is chosen only when a launch has >= 16384 waves of segments - i.e. by the
+    full-size tests at r = 128 / 256.  Forced here (TMF_WSUM_PER_GROUP=1) for every row geometry of 16 lanes and more, both
+    storage types, with user-blocked lists and a heavy item cut into several segments."""
+    monkeypatch.setenv('TMF_WSUM_PER_GROUP', '1')
+    monkeypatch.setenv('TMF_USER_CHUNKS', '3')
+    rng = np.random.default_rng(r)
+    m, n, S_ = 1400, 23, 9                       # ~550 entries per (user block, item) list; item 0: > 1024 entries in a block
+    A = (rng.random((m, n)) < 0.2) * rng.integers(1, 6, (m, n))
+    A[:, 0] = 1
+    idx = np.argwhere(A != 0)
+    val = A[A != 0].astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([np.concatenate([[0], rng.choice(np.arange(1, n), S_ - 1, replace=False)]) for _ in range(m)])   # everyone samples item 0
+    lr = 0.01
+    if dtype == 'f32':
+        check_one_step(tm, U0, V0, idx, val, (m, n), lr, 'wmrb', R, n, S_)
+        return
+    from oracle import sparse_ref as S
+    U0, V0 = _bf16(U0), _bf16(V0)
+    kw = dict(user_weight_graph=tm.Fixed(U0), item_weight_graph=tm.Fixed(V0), loss_graph=tm.WMRB(), n_users=m, n_items=n, n_samples=S_)
+    model = tm.MF(r, **kw)
+    model.random_ind, model.verbose, model.factor_dtype = torch.as_tensor(R), False, torch.bfloat16
+    model.fit(1, tm.eye(m), tm.eye(n), tm.Sparse(idx, val, (m, n)), lr=lr)
+    U1, V1, mean, _ = S.wmrb_epoch(U0.astype(np.float64), V0.astype(np.float64), idx, val.astype(np.float64), R, n, S_, lr)
+    assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+    dV = np.abs(model.item_embedding.float().cpu().numpy() - V1)
+    assert (dV <= 2 ** -8 * np.abs(V1) + 1e-6).mean() > 0.99 and dV.max() <= 2 * lr + 0.01
+
+
 def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
     """TMF_USER_CHUNKS > 1: item lists split by user block, every segment through slab + combine."""
     g = golden('wmrb_small')
