@@ -379,7 +379,8 @@ class Workload:
         self.wplan, self.R = None, None
         if loss == 'wmrb':
             self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
-            ns, sliced = _engine.choose_wmrb_user_pass(m, n, ld, S, self.plan.n_pos, r)
+            ns, sliced = _engine.choose_wmrb_user_pass(m, n, _lib.padded_ld(r, torch.bfloat16) if dtype == 'bf16' else ld, S, self.plan.n_pos, r,
+                                                       elem_size=2 if dtype == 'bf16' else 4)
             self.wplan = _engine.WmrbPlan(self.plan, self.R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n),
                                           item_slices=ns, n_components=r, sliced=sliced)
         self.st = _engine.TrainState(U0, V0, self.plan, r, self.wplan, dtype=torch.bfloat16 if dtype == 'bf16' else torch.float32)

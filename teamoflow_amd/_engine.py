@@ -231,7 +231,7 @@ def mse_user_chunks():
     return max(1, int(env)) if env else 1
 
 
-def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20):
+def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20, elem_size=4):
     """Number of item slices of the sliced WMRB user pass; 1 = the fused single-kernel pass.
 
     The sliced pass keeps every user's negatives sorted by item and walks the catalog in ~4 MB slices
@@ -243,23 +243,24 @@ def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20):
     env = os.environ.get('TMF_ITEM_SLICES')
     if env:
         return max(1, int(env))
-    if n_items * ld * 4 <= 2 * target_bytes:
+    # slices of ~4 MB of V rows in the table's OWN storage type (bf16 rows are half as long: C4 bf16 7 slices 65.4 ms, 13 68.0)
+    if n_items * ld * elem_size <= 2 * target_bytes:
         return 1
-    return int(min(-(-n_items * ld * 4 // target_bytes), 64))
+    return int(min(-(-n_items * ld * elem_size // target_bytes), 64))
 
 
 SLICED_MIN_HINGE_TERMS = 1 << 16   # positives x negatives per user from which the O((S + P) log P) hinge step pays
 SLICED_MIN_SCORES = 1 << 21        # n_users x n_samples below which the epoch is launch-bound and one fused kernel wins
 
 
-def choose_wmrb_user_pass(n_users, n_items, ld, n_samples, n_positives, n_components):
+def choose_wmrb_user_pass(n_users, n_items, ld, n_samples, n_positives, n_components, elem_size=4):
     """(item_slices, sliced) for a WMRB fit.  Large catalogs: the sliced pass with ~4 MB slices (default_item_slices).
     Small catalogs (V in the L2s, scores in LDS) default to the one-kernel pass, whose hinge step costs P_u x S terms per
     user - at the MovieLens-1M shape (C3: 6040 x 3706, S = 1853, 165 positives per user) that is 3e5 terms per user and
     the sliced pass with its O((S + P) log P) hinge kernel is faster although the catalog needs no slicing: 0.37 ms
     against 0.61 ms per user pass, item pass 0.20 against 0.26 (sorted negatives) - profiles/r02_hinge_rewrite.txt item 11.
     The slice count then only provides workgroups (the kernels also shrink their user groups, tmf_wmrb.hip)."""
-    ns = default_item_slices(n_items, ld)
+    ns = default_item_slices(n_items, ld, elem_size=elem_size)
     if ns > 1 or not fused_user_pass_fits(n_samples, n_components) or os.environ.get('TMF_FORCE_SLICED') == '1':
         return ns, True
     if os.environ.get('TMF_ITEM_SLICES') or os.environ.get('TMF_FORCE_FUSED') == '1':
@@ -267,7 +268,7 @@ def choose_wmrb_user_pass(n_users, n_items, ld, n_samples, n_positives, n_compon
     if (n_positives / max(n_users, 1)) * n_samples >= SLICED_MIN_HINGE_TERMS and n_users * n_samples >= SLICED_MIN_SCORES:
         groups = -(-n_users // 16)
         # slices: enough workgroups for a small user count, and no slice larger than one XCD L2 once the pass is sliced anyway
-        return int(max(min(max(round(1400 / groups), 1), 8), -(-n_items * ld * 4 // (4 << 20)))), True
+        return int(max(min(max(round(1400 / groups), 1), 8), -(-n_items * ld * elem_size // (4 << 20)))), True
     return 1, False
 
 

@@ -48,7 +48,8 @@ def fit_minibatch(model, epochs, n_users, n_items, interactions, lr, U0, V0, bat
                                        user_chunks=1 if wmrb else _engine.mse_user_chunks(), csc=not wmrb)
         wplan = None
         if wmrb:
-            ns, sliced = _engine.choose_wmrb_user_pass(b1 - b0, n_items, ld, int(R.shape[1]), plan.n_pos, r)
+            ns, sliced = _engine.choose_wmrb_user_pass(b1 - b0, n_items, ld, int(R.shape[1]), plan.n_pos, r,
+                                                       elem_size=2 if dtype is torch.bfloat16 else 4)
             wplan = _engine.WmrbPlan(plan, R[b0:b1].contiguous(), user_chunks=_engine.default_user_chunks(b1 - b0, ld, n_items=n_items),
                                      item_slices=ns, n_components=r, sliced=sliced)
         states.append(_engine.TrainState(U0[b0:b1], None, plan, r, wplan, dtype=dtype, V_tables=tuple(tables), scratch=scratch))
