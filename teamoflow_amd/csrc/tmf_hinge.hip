@@ -29,7 +29,7 @@ constexpr int HK = 256;             // slots of a chunk's sorted threshold array
 constexpr int HCHUNK = HK - 1;      // entries per chunk: at least one +inf slot stays, so rho <= HK - 1
 constexpr int HPAD = HK + HK / 32;  // slot i lives at i + (i >> 5): the search's reads spread over the banks
 constexpr int HSPL = 8;             // samples per lane and tile (a tile = 512 samples)
-constexpr int HWAVES = 4;
+constexpr int HWAVES = 1;             // one user = one wave = one workgroup: 5.0 ms at C4 against 5.85 with four users per workgroup (8: 7.1)
 
 struct HingeLds {                   // per wave, 5440 bytes
     unsigned long long keys[HK];    // sort keys (orderable(t) << 32 | index); afterwards the fixed-point bucket sums

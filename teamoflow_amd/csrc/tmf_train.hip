@@ -9,7 +9,7 @@
 
 namespace tmf {
 
-constexpr int kWavesPerBlock = 4;   // 256 threads: four independent waves, no LDS, no barrier
+constexpr int kWavesPerBlock = 2;   // independent waves, no barrier; 2 per workgroup measured best (C4 item pass 32.1 ms; 4: 32.5, 8: 36.6; MSE epoch 11.1 vs 11.45)
 constexpr int kUnroll = 4;          // list entries a group keeps in flight
 
 struct SegView {
