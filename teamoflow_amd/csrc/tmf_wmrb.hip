@@ -372,6 +372,11 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 // removed; see profiles/r01_sliced_user_pass.txt.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kSliceUsers = 16;   // users per workgroup of the slice kernels (SliceLists::upg)
+// Waves per workgroup of the slice kernels: 4, or 8 when a (user, slice) range is long (C4 fp32: 86 rows).  With 512-byte rows
+// eight waves are 16 lane groups = ONE user per lane group, and the workgroup retires when its users are done.  Same box,
+// C4 fp32 epoch (scores / gradU ms): 4 waves x 16 users 95.7 (28.15 / 27.6), 4 x 8 95.0, 8 x 16 94.1 (27.4 / 26.8), 16 x 32 94.0,
+// 2 x 4 95.5; config-5 shard (18 rows per range) 4 waves 241.9, 8 waves 249.7; C4 bf16 (16-lane rows) 62.6 / 63.0 - no gain.
+constexpr int kLongRange = 48;   // mean rows per (user, slice) range from which the 8-wave form is used
 
 template <int G>
 struct Stage {
@@ -458,11 +463,11 @@ __device__ __forceinline__ const T* window_base(const T* V, int item_base) {
     return V - (int64_t)item_base * (4 * G * NV);
 }
 
-template <int G, int NV, typename T>
-__global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T* __restrict__ U, const T* __restrict__ V,
+template <int G, int NV, typename T, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_wmrb_scores3(SliceLists a, const T* __restrict__ U, const T* __restrict__ V,
                                                            float* __restrict__ sp, float* __restrict__ p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NG = 64 / G, NGB = NG * kWaves;
+    constexpr int NG = 64 / G, NGB = NG * WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
     int* ids = slice_stage<G>(smem_raw, gid);
@@ -486,12 +491,12 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_scores3(SliceLists a, const T
 
 // slice_first >= 0: this launch covers ONE slice (slice_first) and writes (accumulate == 1) or adds (2) into the
 // single-layer `part` (plain read-modify-write; launches of consecutive slices are ordered by the stream).
-template <int G, int NV, typename T>
-__global__ __launch_bounds__(kThreads) void k_wmrb_gradu3(SliceLists a, const T* __restrict__ V, const float* __restrict__ D,
+template <int G, int NV, typename T, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_wmrb_gradu3(SliceLists a, const T* __restrict__ V, const float* __restrict__ D,
                                                           const float* __restrict__ delta, float* __restrict__ part,
                                                           int slice_first, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NG = 64 / G, NGB = NG * kWaves;
+    constexpr int NG = 64 / G, NGB = NG * WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
     int* ids = slice_stage<G>(smem_raw, gid);
@@ -585,7 +590,7 @@ extern "C" int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col
 }
 
 // ---- sliced pass: storage-type generic implementations + the _f32 / _bf16 entry points ----
-static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what, int lanes_per_row) {
+static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what, int lanes_per_row, int waves) {
     TMF_REQUIRE(l != nullptr, "%s: lists is null", what);
     TMF_REQUIRE(l->n_users >= 0 && l->n_slices > 0 && l->n_samples > 0, "%s: n_users=%d n_slices=%d n_samples=%d", what,
                 l->n_users, l->n_slices, l->n_samples);
@@ -593,7 +598,7 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
     // users per workgroup: 16 (one or two per lane group).  Small groups balance skewed users and leave no tail: against 128
     // per workgroup, same box - C4 99.2 vs 100.4 ms, config-5 shard 249.6 vs 254.7, 200K x 50K r=64 6.99 vs 7.40,
     // 20K x 200K r=128 2.61 vs 3.59, MovieLens-1M shape user pass 0.37 vs 1.07 ms.  TMF_SLICE_USERS overrides (A/B runs).
-    const int lane_groups = (64 / (lanes_per_row > 0 ? lanes_per_row : 64)) * kWaves;   // narrow rows: many lane groups per workgroup
+    const int lane_groups = (64 / (lanes_per_row > 0 ? lanes_per_row : 64)) * waves;   // narrow rows: many lane groups per workgroup
     int upg = kSliceUsers > lane_groups ? kSliceUsers : lane_groups;                    // at least one user for each of them
     if (const char* env = getenv("TMF_SLICE_USERS")) {
         const int v = atoi(env);
@@ -609,8 +614,18 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
     return TMF_OK;
 }
 
-static size_t slice_lds(const RowGeom& geom) {
-    return (size_t)(64 / (geom.G ? geom.G : 1)) * kWaves * 2 * 8 * geom.G * sizeof(int);
+static size_t slice_lds(const RowGeom& geom, int waves) {
+    return (size_t)(64 / (geom.G ? geom.G : 1)) * waves * 2 * 8 * geom.G * sizeof(int);
+}
+
+// 8 waves per workgroup for long ranges, 4 otherwise (kLongRange); TMF_SLICE_WAVES = 4 | 8 forces one form (A/B runs, tests)
+static int slice_waves(const tmf_slice_lists* l, int lanes_per_row) {
+    if (const char* env = getenv("TMF_SLICE_WAVES")) {
+        const int v = atoi(env);
+        if (v == 4 || v == 8) return v;
+    }
+    // rows of 32 lanes and more: four waves are only 8 lane groups (narrower rows already have one group per user)
+    return (l && l->n_slices > 0 && l->n_samples / l->n_slices >= kLongRange && lanes_per_row >= 32) ? 8 : 4;
 }
 
 template <typename T>
@@ -618,15 +633,20 @@ static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const 
                              int n_components, void* stream) {
     SliceLists a;
     const RowGeom geom = row_geom_of<T>(n_components);
-    if (int rc = check_lists(lists, a, "wmrb_scores3", geom.G)) return rc;
+    const int waves = slice_waves(lists, geom.G);
+    if (int rc = check_lists(lists, a, "wmrb_scores3", geom.G, waves)) return rc;
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(U && V && sp && (p || lists->col == nullptr), "wmrb_scores3: null pointer");
-    const size_t lds = slice_lds(geom);
-#define CALL(G_, NV_)                                                                                              \
-    hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(kThreads), lds, \
+    const size_t lds = slice_lds(geom, waves);
+#define CALLW(G_, NV_, W_)                                                                                             \
+    hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T, W_>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(64 * W_), lds, \
                        (hipStream_t)stream, a, (const T*)U, (const T*)V, sp, p)
-    TMF_DISPATCH(T, geom, CALL);
-#undef CALL
+#define CALL4(G_, NV_) CALLW(G_, NV_, 4)
+#define CALL8(G_, NV_) CALLW(G_, NV_, 8)
+    if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
+#undef CALL4
+#undef CALL8
+#undef CALLW
     return check_launch("tmf_wmrb_scores3");
 }
 
@@ -635,27 +655,36 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
                             int per_slice_launches, int n_components, void* stream) {
     SliceLists a;
     const RowGeom geom = row_geom_of<T>(n_components);
-    if (int rc = check_lists(lists, a, "wmrb_gradu3", geom.G)) return rc;
+    const int waves = slice_waves(lists, geom.G);
+    if (int rc = check_lists(lists, a, "wmrb_gradu3", geom.G, waves)) return rc;
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
-    const size_t lds = slice_lds(geom);
+    const size_t lds = slice_lds(geom, waves);
     TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 2, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
     if (per_slice_launches) {
         for (int sl = a.sl0; sl < a.sl0 + a.nsl; ++sl) {
             const int accumulate = (sl == a.sl0 && per_slice_launches == 1) ? 1 : 2;
-#define CALL(G_, NV_)                                                                                                    \
-    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)a.n_groups), dim3(kThreads), lds, (hipStream_t)stream, a, \
+#define CALLW(G_, NV_, W_)                                                                                                   \
+    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T, W_>), dim3((unsigned)a.n_groups), dim3(64 * W_), lds, (hipStream_t)stream, a, \
                        (const T*)V, D, delta, part, sl, accumulate)
-            TMF_DISPATCH(T, geom, CALL);
-#undef CALL
+#define CALL4(G_, NV_) CALLW(G_, NV_, 4)
+#define CALL8(G_, NV_) CALLW(G_, NV_, 8)
+            if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
+#undef CALL4
+#undef CALL8
+#undef CALLW
         }
         return check_launch("tmf_wmrb_gradu3");
     }
-#define CALL(G_, NV_)                                                                                        \
-    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(kThreads), lds, \
+#define CALLW(G_, NV_, W_)                                                                                   \
+    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T, W_>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(64 * W_), lds, \
                        (hipStream_t)stream, a, (const T*)V, D, delta, part, -1, 0)
-    TMF_DISPATCH(T, geom, CALL);
-#undef CALL
+#define CALL4(G_, NV_) CALLW(G_, NV_, 4)
+#define CALL8(G_, NV_) CALLW(G_, NV_, 8)
+    if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
+#undef CALL4
+#undef CALL8
+#undef CALLW
     return check_launch("tmf_wmrb_gradu3");
 }
 
