@@ -1,8 +1,9 @@
 #!/bin/bash
-# Config-5 shard (1.25M x 1M, r=256, bf16) epoch by (experiment knob, item slices[, user blocks]); on the box: bash tools/c5_sweep.sh "0:64 0:128:134"
+# Config-5 shard (1.25M x 1M, r=256, bf16) epoch by (slice-kernel waves per workgroup 4|8, item slices[, user blocks]); on the box:
+#   bash tools/c5_sweep.sh "4:64 8:64 4:128:134"
 for c in $1; do
   IFS=: read flat ns uc <<< "$c"
-  export TMF_FLAT=$flat TMF_ITEM_SLICES=$ns
+  export TMF_SLICE_WAVES=$flat TMF_ITEM_SLICES=$ns
   if [ -n "$uc" ]; then export TMF_USER_CHUNKS=$uc; else unset TMF_USER_CHUNKS; fi
   timeout -k 10 300 python bench.py --users 1250000 --items 1000000 --rank 256 --nnz 125000000 --dtype bf16 --no-extras --steps 5 --warmup 2 > gpurun_out/c5_${flat}_${ns}.json 2>gpurun_out/c5_sweep.err || { echo "run $c failed"; tail -3 gpurun_out/c5_sweep.err; exit 1; }
   python -c "
