@@ -9,8 +9,10 @@ unit the reference times at matrix_factorization.py:129-177.  Workload = BASELIN
 configuration: 1M users x 100K items, r = 128, WMRB with S = 1024 static negatives, ~1e8 interactions
 ("C4"), fp32, synthetic data generated on the device.  With N > 1 the users are split over
 the ranks, V is replicated and its gradient is exchanged by RCCL reduce-scatter / all-gather
-(teamoflow_amd/dist.py): `--scaling weak` gives every rank its own 1M users, `--scaling strong` splits the
-ONE 1M-user problem (BASELINE config 4 as written) into contiguous cost-balanced user blocks.
+(teamoflow_amd/dist.py).  Default for N > 1 is STRONG scaling: the ONE 1M-user problem (BASELINE config 4 as written) cut
+into contiguous cost-balanced user blocks; `--scaling weak` gives every rank its own 1M users and says so in the line.
+The default N = 1 run also times one rank's shard of the 8-way split on this one GPU (`strong_scaling_projection`: a
+PROJECTION of the 1 -> 8 curve from measured shard time + modelled wire time, not a measured N > 1 run).
 Rank 0 prints ONE JSON line; DESIGN.md §4 defines every field of its `roofline` object.
 """
 import argparse
@@ -454,6 +456,90 @@ def hbm_leg(args, dev, name, m, n, nnz, r, S, loss, dtype, steps, warmup):
     return out
 
 
+XGMI_LINKS, XGMI_LINK_BPS = 7, 153e9   # per GPU: 7 point-to-point links x ~153 GB/s (the task's hardware notes)
+
+
+def strong_scaling_projection(args, dev, full_ms, full_kernel_ms, G=8, steps=5, warmup=2):
+    """What ONE rank of the G-way strong split of this workload does, timed on this one GPU, and the 1 -> G scaling it
+    projects to.  NOT a measured N > 1 run: the shard's compute (local passes with the raw-gradient epilogue for V,
+    tmf_adam_fresh_rows on the rank's 1/G of V) is measured; the wire time of the two collectives is MODELLED from their byte
+    counts over 7 xGMI links; the 1-rank RCCL calls are measured only as a call floor (no peer: a device-local copy).
+    The reference loop being split: /root/reference/src/teamoflow/mf/matrix_factorization.py:128-176."""
+    out = dict(label=f'PROJECTION from one GPU - no N > 1 run has been measured; G = {G}', G=G, full_problem_ms=full_ms, shards={})
+    worst, worst_kernels = 0.0, {}
+    for rank in (0, G - 1):
+        wl = Workload(args, args.users, args.items, args.nnz, args.r, args.samples, args.loss, args.dtype, rank, G, dev, strong=True)
+        backend = tdist.HipBackend(wl.st, args.loss, wl.c, wl.adam, prof=None)
+        st, rows = wl.st, wl.n_pad // G
+        prof = _engine.KernelTimer()
+
+        def step(p):
+            backend.prof = p
+            gV, _ = backend.local_passes()
+            if p:
+                p.start('v_table_copy_and_adam_shard')
+            st.V_nxt.copy_(st.V)                                   # stands in for the local part of the all-gather
+            backend.adam_rows(st.V_nxt[rank * rows:(rank + 1) * rows], gV[rank * rows:(rank + 1) * rows])
+            if p:
+                p.stop('v_table_copy_and_adam_shard')
+            backend.finish()
+        for _ in range(warmup):
+            step(None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(prof)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        kern = {k: prof.mean_ms(k) for k in prof.spans}
+        out['shards'][f'rank{rank}'] = dict(users=wl.m, interactions=wl.nnz, ms_per_epoch=ms, kernels_ms=kern)
+        if ms > worst:
+            worst, worst_kernels = ms, kern
+        del wl, backend, st
+        torch.cuda.empty_cache()
+    # collectives: bytes every rank puts on the wire, spread over its 7 links (reduce-scatter and all-gather are all-to-all
+    # shaped on a fully connected xGMI node: (G-1)/G of the table leaves through G-1 <= 7 links at once)
+    ld = _lib.padded_ld(args.r, torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    n_pad = tdist.padded_rows(args.items, G)
+    rs_bytes = (G - 1) / G * n_pad * ld * 4
+    ag_bytes = (G - 1) / G * n_pad * ld * (2 if args.dtype == 'bf16' else 4)
+    links = min(G - 1, XGMI_LINKS)
+    wire_ms = (rs_bytes + ag_bytes) / (links * XGMI_LINK_BPS) * 1e3
+    floor = None
+    try:
+        import torch.distributed as dist
+        own = not dist.is_initialized()
+        if own:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29578')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        a = torch.zeros(n_pad, ld, device=dev)
+        b = torch.empty_like(a)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for i in range(3):   # the first call builds the communicator
+            ev[0].record(); dist.reduce_scatter_tensor(b, a); ev[1].record()
+            ev[2].record(); dist.all_gather_into_tensor(a, b); ev[3].record()
+        torch.cuda.synchronize()
+        floor = dict(reduce_scatter_ms=ev[0].elapsed_time(ev[1]), all_gather_ms=ev[2].elapsed_time(ev[3]),
+                     note='RCCL with ONE rank: no peer, a device-local copy of the whole table - a floor for the call, not a wire time')
+        if own:
+            dist.destroy_process_group()
+    except Exception as e:   # the projection does not depend on it
+        floor = dict(error=repr(e))
+    call_ms = (floor.get('reduce_scatter_ms', 0.0) + floor.get('all_gather_ms', 0.0)) if floor else 0.0
+    t_G = worst + wire_ms + call_ms
+    # what does not shrink with G: per kernel, the shard's time beyond 1/G of the full problem's
+    fixed = {k: dict(full_ms=full_kernel_ms.get(k), shard_ms=v, beyond_ideal_ms=(v - full_kernel_ms[k] / G) if k in full_kernel_ms else v)
+             for k, v in worst_kernels.items()}
+    out.update(slowest_shard_ms=worst, wire_ms_modelled=wire_ms, wire_model=f'(reduce-scatter {rs_bytes / 1e6:.1f} MB + all-gather {ag_bytes / 1e6:.1f} MB per rank) '
+               f'/ ({links} links x {XGMI_LINK_BPS / 1e9:.0f} GB/s)', rccl_one_rank_floor=floor, projected_ms_per_epoch=t_G,
+               projected_scaling=full_ms / t_G, ideal_scaling=G, per_kernel_beyond_ideal=fixed,
+               fixed_costs_note='beyond_ideal_ms > 0: the part of a kernel that does not shrink with G - the item pass still walks all '
+                                'items (one partial row per (user block, item) list, V-sized slab + combine over the whole catalog), '
+                                'the Adam step / table copy touch V-sized data, short per-user ranges lose their slice efficiency')
+    return out
+
+
 def api_fit(dev, wl, args, epochs, shard_items=0):
     """The same workload through the PUBLIC class surface: MatrixFactorization(...).fit(epochs) - plan build and epoch loop
     timed by the model itself (plan_seconds_, fit_seconds_).  shard_items = q > 0: the item-row-sharded form (one rank
@@ -559,8 +645,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
-                    help='N > 1: weak = every rank its own --users users; strong = the one --users problem split over the ranks')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                    help='N > 1: strong (default) = the ONE --users x --items problem split over the ranks - BASELINE config 4 as '
+                         'written; weak = every rank its own --users users (labelled as such in the JSON line)')
+    ap.add_argument('--no-projection', action='store_true', help='skip the one-GPU timing of the 8-way strong-scaling shard')
     ap.add_argument('--users', type=int, default=1_000_000)
     ap.add_argument('--items', type=int, default=100_000)
     ap.add_argument('--rank', type=int, default=128, dest='r')
@@ -667,11 +755,14 @@ def main():
 
     out = dict(metric='train_interactions_per_sec', value=nnz_total / (elapsed / args.steps), unit='interactions/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
-               scaling=args.scaling if world > 1 else 'weak', vs_baseline=None,
+               scaling=args.scaling, vs_baseline=None,
                dtype='f32' if args.dtype == 'f32' else 'bf16 storage / f32 arithmetic',
                data='synthetic' + (' (REHEARSAL: all ranks on one card, host-staged gloo collectives - timings invalid)' if rehearse else ''),
                config=dict(workload=wl.describe('C4' if (args.users, args.items, args.r) == (1_000_000, 100_000, 128) else 'custom')
-                           + (f' (strong scaling: users {wl.user_block[0]}..{wl.user_block[1]} of {args.users} on rank 0)' if strong and world > 1 else ''),
+                           + (f' (strong scaling: ONE problem over {world} ranks, users {wl.user_block[0]}..{wl.user_block[1]} of {args.users} on rank 0)'
+                              if strong and world > 1 else '')
+                           + (f' (WEAK scaling: every one of the {world} ranks has its own {args.users} users - not BASELINE config 4 as written)'
+                              if not strong and world > 1 else ''),
                            interactions_per_gpu=wl.nnz, interactions_total=nnz_total, positives_per_gpu=wl.plan.n_pos,
                            parallelism=f'user-partition dp{world}', lr=args.lr, warmup_ms_per_step=warm_elapsed / max(args.warmup, 1) * 1e3),
                roofline=roofline)
@@ -727,6 +818,16 @@ def main():
             out['recall_at_10']['end_to_end_C2'] = dict(engine=c2['recall_at_10'], oracle=c2['recall_at_10_cpu_restatement'],
                                                         abs_diff=c2['recall_at_10_abs_diff'],
                                                         case='C2 (943 x 1682, r=32, MSE): 100 epochs trained by each side from the same start')
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_projection and default_workload:
+        try:
+            wl.st = None
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        kms = {k: prof.mean_ms(k) for k in prof.spans}
+        out['strong_scaling_projection'] = strong_scaling_projection(args, dev, ms_per_step, kms)
+        log(f"[bench] projected 1 -> 8 scaling {out['strong_scaling_projection']['projected_scaling']:.2f}x "
+            f"(slowest shard {out['strong_scaling_projection']['slowest_shard_ms']:.2f} ms, full problem {ms_per_step:.2f} ms)")
     if rank == 0 and world == 1 and not args.no_extras and not args.no_legs and default_workload:
         # workloads whose factor rows really come from HBM (the C4 tables sit in L2 / Infinity Cache): DESIGN.md §4
         del wl

@@ -171,6 +171,10 @@ typedef struct tmf_slice_lists {
      * [slice_begin, slice_begin + slice_count) and the V pointer of the call addresses item row `item_base` (the first row
      * of the window).  All three 0 = the whole catalog. */
     int32_t slice_begin, slice_count, item_base;
+    /* Block order of the slice kernels (speed only): 0 = slice-major (every resident workgroup walks the same slice, each
+     * XCD L2 holds a copy of it), 1 = XCD-major (the XCD of block b - b mod 8 under the observed round-robin placement -
+     * walks the slices slice_begin + 8 i + (b mod 8): eight different slices resident, one per L2). */
+    int32_t xcd_major;
 } tmf_slice_lists;
 /* Kernels, called in this order on one stream (tables float (_f32) or bf16 (_bf16) rows as void*; sp / p / D / delta /
  * part / w_ent are fp32):
@@ -180,9 +184,12 @@ typedef struct tmf_slice_lists {
  *                       per_slice_launches = 0: one launch, part is [n_slices * n_users, ld], finish gets n_slices;
  *                       per_slice_launches = 1: one launch per slice adding into ONE [n_users, ld] layer (memory-light;
  *                       finish is then called with n_slices = 1); the first slice launched overwrites the layer;
- *                       per_slice_launches = 2: the same, but the first slice launched adds to the layer as well (the
+ *                       per_slice_launches = 3: one launch per ROUND of eight slices into EIGHT layers (part is
+ *                       [8 * n_users, ld]; the slice slice_begin + 8 i + x goes to layer x; finish gets min(8, slices));
+ *                       per_slice_launches = 2: the same as 1, but the first slice launched adds to the layer as well (the
  *                       later windows of a windowed pass)
- *   tmf_wmrb_finish_*   U_out[u] = epilogue(sum_slice part[slice][u]) */
+ *   tmf_wmrb_finish_*   U_out[u] = epilogue(sum_slice part[slice][u]); with TMF_EPI_GRAD, U_out == part is allowed (the
+ *                       layers are summed in place into layer 0) */
 int tmf_wmrb_scores3_f32(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,
                          int n_components, void* stream);
 int tmf_wmrb_scores3_bf16(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,

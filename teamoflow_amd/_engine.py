@@ -249,6 +249,16 @@ def default_item_slices(n_items, ld, n_samples=None, target_bytes=4 << 20, elem_
     return int(min(-(-n_items * ld * elem_size // target_bytes), 64))
 
 
+def slices_xcd_major(n_slices):
+    """Block order of the slice kernels (tmf_slice_lists.xcd_major): every XCD its own slice (eight resident at a time) or all
+    of them the same one.  TMF_SLICE_XCD = 0 | 1 forces it (the library reads the same variable)."""
+    env = os.environ.get('TMF_SLICE_XCD')
+    if env in ('0', '1'):
+        return env == '1'
+    return XCD_MAJOR_DEFAULT and n_slices >= 8
+
+
+XCD_MAJOR_DEFAULT = False
 SLICED_MIN_HINGE_TERMS = 1 << 16   # positives x negatives per user from which the O((S + P) log P) hinge step pays
 SLICED_MIN_SCORES = 1 << 21        # n_users x n_samples below which the epoch is launch-bound and one fused kernel wins
 
@@ -290,11 +300,13 @@ class WmrbPlan:
     Sliced pass (``sliced``): ``R`` holds every user's negatives in ascending item order, ``slice_off`` / ``pos_off`` the first
     negative / interaction of every item slice."""
 
-    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128, sliced=None, item_lists=True):
+    def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128, sliced=None, item_lists=True,
+                 xcd_major=None):
         dev = R.device
         m, S = R.shape
         nnz, n = plan.nnz, plan.n_items
         self.S, self.n_slices = S, max(1, int(item_slices))
+        self.xcd_major = slices_xcd_major(self.n_slices) if xcd_major is None else bool(xcd_major)
         self.sliced = bool(sliced) if sliced is not None else (self.n_slices > 1 or not fused_user_pass_fits(S, n_components))
         C = self.user_chunks = max(1, int(user_chunks))
         E = nnz + m * S
@@ -374,7 +386,8 @@ class WmrbPlan:
         if self._lists is None:
             m, S = self.R.shape
             self._lists = _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(),
-                                          plan.col_u.data_ptr(), self.pos_off.data_ptr(), m, S, self.n_slices)
+                                          plan.col_u.data_ptr(), self.pos_off.data_ptr(), m, S, self.n_slices, 0, 0, 0,
+                                          int(self.xcd_major))
         return ctypes.byref(self._lists)
 
     def window_lists(self, plan, slice_begin, slice_count, item_base):
@@ -420,8 +433,15 @@ class TrainState:
                     loss_part=max(plan.seg_u.nseg, plan.n_users, 1))
         if wplan is not None and wplan.sliced:
             m, S = wplan.R.shape
-            # gradU partials: one layer per slice, or (above PART_BUDGET bytes) a single layer summed by per-slice launches
-            self.part_layers = wplan.n_slices if wplan.n_slices * m * self.ld * 4 <= PART_BUDGET else 1
+            # gradU partials: one layer per slice, or (above PART_BUDGET bytes) a single layer summed by per-slice launches -
+            # eight layers summed by per-round launches when the slices are walked XCD-major
+            ns = wplan.n_slices
+            if ns * m * self.ld * 4 <= PART_BUDGET:
+                self.part_layers, self.gradu_launches = ns, 0          # one launch, a layer per slice
+            elif wplan.xcd_major:
+                self.part_layers, self.gradu_launches = min(8, ns), 3  # a launch per round of eight slices
+            else:
+                self.part_layers, self.gradu_launches = 1, 1           # a launch per slice
             need.update(sp=m * S, pk=max(plan.nnz, 1), part=self.part_layers * max(m, 1) * self.ld)
         self._need = need
         if scratch is None:
@@ -540,7 +560,8 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None, user_epi=_lib.EPI_ADAM, 
     timed('wmrb_hinge', lambda: lib.tmf_wmrb_hinge2(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(st.pk), _lib.ptr(st.sp),
                                                     i32(m), i32(S), c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), s))
     timed('wmrb_gradu', lambda: getattr(lib, 'tmf_wmrb_gradu3' + st.sfx)(
-        lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(st.V), _lib.ptr(st.part), int(st.part_layers == 1 and ns > 1), r, s))
+        lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(st.V), _lib.ptr(st.part),
+        st.gradu_launches, r, s))
     timed('wmrb_finish', lambda: getattr(lib, 'tmf_wmrb_finish' + st.sfx)(_lib.ptr(st.part), i32(st.part_layers), i32(m),
                                                                           _lib.ptr(st.U), _lib.ptr(st.U_nxt if U_out is None else U_out),
                                                                           r, user_epi, adam, s))

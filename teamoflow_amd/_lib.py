@@ -33,7 +33,7 @@ class SliceLists(ctypes.Structure):
     _fields_ = [('R_sorted', ctypes.c_void_p), ('slice_off', ctypes.c_void_p), ('rowptr', ctypes.c_void_p),
                 ('col', ctypes.c_void_p), ('pos_off', ctypes.c_void_p), ('n_users', ctypes.c_int32),
                 ('n_samples', ctypes.c_int32), ('n_slices', ctypes.c_int32), ('slice_begin', ctypes.c_int32),
-                ('slice_count', ctypes.c_int32), ('item_base', ctypes.c_int32)]
+                ('slice_count', ctypes.c_int32), ('item_base', ctypes.c_int32), ('xcd_major', ctypes.c_int32)]
 
 
 class Segments(ctypes.Structure):

@@ -312,6 +312,14 @@ __device__ __forceinline__ void add(Frag<NV>& acc, const Frag<NV>& x) {
     }
 }
 
+// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware completes a wave's LDS
+// operations in issue order, so no s_barrier is needed - this only keeps the compiler from moving the accesses
+// across the hand-over (it emits no instruction beyond the s_waitcnt the reads need anyway).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Sum over the G lanes of a group (lanes [G*k, G*k+G)); every lane of the group ends with the same bits
 // (x+y == y+x at every level), so the value can be used as a per-entry weight by all of them.
 // Pure VALU: DPP quad permutes (lane^1, lane^2), row_half_mirror / row_mirror (the other quad / the other

@@ -39,12 +39,6 @@ struct HingeLds {                   // per wave, 5440 bytes
     unsigned char ord[HK];          // chunk-local index of the entry at a sorted position
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave complete in issue order; this only keeps the compiler from moving them
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 __device__ __forceinline__ unsigned int orderable(float t) {
     const unsigned int u = __float_as_uint(t);
     return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);

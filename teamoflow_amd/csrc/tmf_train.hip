@@ -129,6 +129,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
             ids[e] = ent_row[t0 + e];
             ws[e] = wbuf[ent_w[t0 + e]];
         }
+        wave_lds_sync();
         // lane group `grp` takes entries grp, grp + NG, ...; a row is only loaded when its weight is not 0
         for (int e0 = grp; e0 < cnt; e0 += NG * kUnroll) {
             Raw<NV, T> raw[kUnroll];
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
             ids[e] = ent_row[t0 + e];
             ws[e] = wbuf[ent_w[t0 + e]];
         }
+        wave_lds_sync();
         for (int e0 = 0; e0 < cnt; e0 += kUnroll) {
             Raw<NV, T> raw[kUnroll];
             float wc[kUnroll];
@@ -307,12 +309,33 @@ __global__ __launch_bounds__(256) void k_adam_state_rows(float4* __restrict__ W,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Deterministic sum: one 1024-thread block, strided fp64 partials, fixed LDS tree.
+// Deterministic sum: one 1024-thread block, fp64 partials per thread in a fixed strided order, fixed LDS tree.
+// The block reads 16 bytes per lane with four loads in flight (~1M partials = 4 MB at C4: 0.42 ms with scalar
+// loads one at a time; this form is bound by what one CU pulls from L2 / HBM).  A second stage over several
+// blocks would need a workspace the ABI does not have; one CU is enough for a few MB.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_sum_f32(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
     __shared__ double sh[1024];
+    constexpr int kInFlight = 4;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)x[i];
+    const int64_t head = (16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15;   // bytes to the first 16-byte boundary
+    const int64_t pre = (head / 4 < n) ? head / 4 : n;                          // scalar prefix
+    if ((int64_t)threadIdx.x < pre) s += (double)x[threadIdx.x];
+    const tmf_f4* x4 = reinterpret_cast<const tmf_f4*>(x + pre);
+    const int64_t n4 = (n - pre) / 4;
+    for (int64_t i = threadIdx.x; i < n4; i += 1024 * kInFlight) {
+        tmf_f4 v[kInFlight];
+#pragma unroll
+        for (int t = 0; t < kInFlight; ++t) {
+            const int64_t k = i + (int64_t)t * 1024;
+            const tmf_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            v[t] = (k < n4) ? __builtin_nontemporal_load(x4 + k) : zero4;
+        }
+#pragma unroll
+        for (int t = 0; t < kInFlight; ++t) s += ((double)v[t][0] + (double)v[t][1]) + ((double)v[t][2] + (double)v[t][3]);
+    }
+    const int64_t tail = pre + 4 * n4;
+    if (tail + threadIdx.x < n) s += (double)x[tail + threadIdx.x];   // fewer than four elements
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int w = 512; w >= 1; w >>= 1) {

@@ -402,6 +402,7 @@ __device__ __forceinline__ void slice_list(int* ids, float* dst, const int32_t* 
             ids[e] = list[t0 + e];
             if (GRADU) dst[e] = wts[t0 + e];
         }
+        wave_lds_sync();
         float keep = 0.f;  // scores: lane g keeps the score of entry (e & (G-1)) == g until G of them are complete
         for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
             Raw<NV, T> raw[kUnrollW];
@@ -454,7 +455,25 @@ struct SliceLists {
     int upg;                 // users per workgroup
     int sl0, nsl;            // slices [sl0, sl0 + nsl) are covered by this launch ...
     int item_base;           // ... and V points at item row item_base (windowed V: only these rows are resident)
+    int xcd;                 // 1: XCD-major block order (slice_of_block)
 };
+
+// Which (slice, user group) a block works on.  Plain order is slice-major: every resident workgroup walks the SAME slice, so
+// each of the 8 XCD L2s holds a copy of it.  XCD-major order (a.xcd) relies on the observed round-robin placement - blocks b
+// and b + 8 share an XCD - and gives XCD x the slices sl0 + 8 i + x: eight DIFFERENT slices are resident at a time, one per
+// L2, and the eight workgroups that visit one user group together share its U rows / offsets through the Infinity Cache.
+// Speed only: both orders enumerate every (slice, group) pair exactly once, whatever the hardware does with the blocks.
+__device__ __forceinline__ bool slice_of_block(const SliceLists& a, int64_t b, int64_t& sl, int64_t& grp) {
+    if (!a.xcd) {
+        sl = a.sl0 + b / a.n_groups;
+        grp = b % a.n_groups;
+        return true;
+    }
+    const int64_t x = b & 7, j = b >> 3;
+    sl = a.sl0 + 8 * (j / a.n_groups) + x;
+    grp = j % a.n_groups;
+    return sl < a.sl0 + a.nsl;
+}
 
 // V rebased so that global item ids index it (rows outside the window are never touched: every id of the launched slices
 // lies inside, idle lanes read row item_base)
@@ -472,7 +491,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_scores3(SliceLists a, const
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
     int* ids = slice_stage<G>(smem_raw, gid);
     float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
-    const int64_t sl = a.sl0 + blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
+    int64_t sl, grp;
+    if (!slice_of_block(a, blockIdx.x, sl, grp)) return;
     const int64_t ubeg = grp * a.upg;
     const int64_t uend = (ubeg + a.upg < a.n_users) ? ubeg + a.upg : a.n_users;
     V = window_base<G, NV, T>(V, a.item_base);
@@ -489,8 +509,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_scores3(SliceLists a, const
     }
 }
 
-// slice_first >= 0: this launch covers ONE slice (slice_first) and writes (accumulate == 1) or adds (2) into the
-// single-layer `part` (plain read-modify-write; launches of consecutive slices are ordered by the stream).
+// slice_first >= 0, accumulate 1 | 2: this launch covers ONE slice (slice_first) and writes (accumulate == 1) or adds (2) into
+// the single-layer `part` (plain read-modify-write; launches of consecutive slices are ordered by the stream).
+// slice_first >= 0, accumulate 3 | 4: this launch covers the ROUND of up to eight slices slice_first + x, x = blockIdx.x & 7
+// (XCD-major order), each into its own layer part[x]: 3 writes the layer, 4 adds to it.
 template <int G, int NV, typename T, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_wmrb_gradu3(SliceLists a, const T* __restrict__ V, const float* __restrict__ D,
                                                           const float* __restrict__ delta, float* __restrict__ part,
@@ -501,7 +523,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_gradu3(SliceLists a, const 
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
     int* ids = slice_stage<G>(smem_raw, gid);
     float* dst = reinterpret_cast<float*>(ids + Stage<G>::tile);
-    const int64_t sl = (slice_first >= 0) ? slice_first : a.sl0 + blockIdx.x / a.n_groups, grp = blockIdx.x % a.n_groups;
+    int64_t sl, grp, layer = 0;
+    if (slice_first < 0) {
+        if (!slice_of_block(a, blockIdx.x, sl, grp)) return;
+    } else if (accumulate >= 3) {
+        layer = blockIdx.x & 7;
+        sl = slice_first + layer;
+        grp = blockIdx.x >> 3;
+        if (sl >= a.sl0 + a.nsl) return;
+        accumulate -= 2;
+    } else {
+        sl = slice_first;
+        grp = blockIdx.x;
+    }
     V = window_base<G, NV, T>(V, a.item_base);
     const int64_t ubeg = grp * a.upg;
     const int64_t uend = (ubeg + a.upg < a.n_users) ? ubeg + a.upg : a.n_users;
@@ -516,20 +550,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_gradu3(SliceLists a, const 
         if (accumulate == 0) {
             store_row_f32<G, NV, T>(acc, part, sl * a.n_users + u, g);
         } else {  // one launch per slice: part is a single [users, ld] layer summed in slice order
+            const int64_t prow = layer * a.n_users + u;
             if (accumulate == 2) {
                 Frag<NV> prev;
-                load_row_f32<G, NV, T>(prev, part, u, g);
+                load_row_f32<G, NV, T>(prev, part, prow, g);
                 add<NV>(prev, acc);
                 acc = prev;
             }
-            store_row_f32<G, NV, T>(acc, part, u, g);
+            store_row_f32<G, NV, T>(acc, part, prow, g);
         }
     }
 }
 
+// `part` and `U_out` are NOT restrict-qualified: with TMF_EPI_GRAD the caller may sum the layers in place (U_out == part,
+// include/tmf.h) - every lane loads all layers of its row before it stores the row.
 template <int G, int NV, typename T>
-__global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* __restrict__ part, int n_slices, int64_t n_users,
-                                                          const T* __restrict__ U_old, void* __restrict__ U_out, int epi,
+__global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* part, int n_slices, int64_t n_users,
+                                                          const T* __restrict__ U_old, void* U_out, int epi,
                                                           tmf_adam adam) {
     constexpr int NG = 64 / G, NGB = NG * kWaves;
     const int lane = threadIdx.x & 63, g = lane & (G - 1);
@@ -609,9 +646,18 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
     const int sl0 = l->slice_begin, nsl = l->slice_count > 0 ? l->slice_count : l->n_slices - sl0;
     TMF_REQUIRE(sl0 >= 0 && nsl > 0 && sl0 + nsl <= l->n_slices && l->item_base >= 0, "%s: window [%d, +%d) of %d slices, item_base=%d",
                 what, sl0, l->slice_count, l->n_slices, l->item_base);
+    int xcd = l->xcd_major != 0;
+    if (const char* env = getenv("TMF_SLICE_XCD")) xcd = env[0] == '1';   // A/B runs
+    const int rounds = (nsl + 7) / 8;
+    TMF_REQUIRE(!xcd || groups * 8 * rounds < ((int64_t)1 << 31), "%s: grid too large", what);
     a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups,
-                   upg, sl0, nsl, l->item_base};
+                   upg, sl0, nsl, l->item_base, xcd};
     return TMF_OK;
+}
+
+// blocks of a launch that covers all slices of `a` (plain order: slice-major; XCD-major: rounds of eight slices)
+static unsigned slice_grid(const SliceLists& a) {
+    return (unsigned)(a.xcd ? a.n_groups * 8 * ((a.nsl + 7) / 8) : a.n_groups * a.nsl);
 }
 
 static size_t slice_lds(const RowGeom& geom, int waves) {
@@ -639,7 +685,7 @@ static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const 
     TMF_REQUIRE(U && V && sp && (p || lists->col == nullptr), "wmrb_scores3: null pointer");
     const size_t lds = slice_lds(geom, waves);
 #define CALLW(G_, NV_, W_)                                                                                             \
-    hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T, W_>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(64 * W_), lds, \
+    hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T, W_>), dim3(slice_grid(a)), dim3(64 * W_), lds, \
                        (hipStream_t)stream, a, (const T*)U, (const T*)V, sp, p)
 #define CALL4(G_, NV_) CALLW(G_, NV_, 4)
 #define CALL8(G_, NV_) CALLW(G_, NV_, 8)
@@ -660,7 +706,22 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
     const size_t lds = slice_lds(geom, waves);
-    TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 2, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
+    TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 3, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
+    if (per_slice_launches == 3) {   // rounds of eight slices, one layer per XCD lane (see k_wmrb_gradu3)
+        for (int sl = a.sl0; sl < a.sl0 + a.nsl; sl += 8) {
+            const int accumulate = (sl == a.sl0) ? 3 : 4;
+#define CALLW(G_, NV_, W_)                                                                                                       \
+    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T, W_>), dim3((unsigned)(a.n_groups * 8)), dim3(64 * W_), lds, (hipStream_t)stream, a, \
+                       (const T*)V, D, delta, part, sl, accumulate)
+#define CALL4(G_, NV_) CALLW(G_, NV_, 4)
+#define CALL8(G_, NV_) CALLW(G_, NV_, 8)
+            if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
+#undef CALL4
+#undef CALL8
+#undef CALLW
+        }
+        return check_launch("tmf_wmrb_gradu3");
+    }
     if (per_slice_launches) {
         for (int sl = a.sl0; sl < a.sl0 + a.nsl; ++sl) {
             const int accumulate = (sl == a.sl0 && per_slice_launches == 1) ? 1 : 2;
@@ -677,7 +738,7 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
         return check_launch("tmf_wmrb_gradu3");
     }
 #define CALLW(G_, NV_, W_)                                                                                   \
-    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T, W_>), dim3((unsigned)(a.n_groups * a.nsl)), dim3(64 * W_), lds, \
+    hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T, W_>), dim3(slice_grid(a)), dim3(64 * W_), lds, \
                        (hipStream_t)stream, a, (const T*)V, D, delta, part, -1, 0)
 #define CALL4(G_, NV_) CALLW(G_, NV_, 4)
 #define CALL8(G_, NV_) CALLW(G_, NV_, 8)

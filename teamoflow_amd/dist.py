@@ -16,6 +16,8 @@ row-sharded for the optimiser:
 The compute is injected (``backend``) so the choreography can be exercised with gloo on CPU
 (tests/test_dist_cpu.py drives it with the NumPy oracle); on the GPU the backend is ``HipBackend``.
 """
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -131,7 +133,9 @@ class DataParallelEpoch:
         self.V_gather = None if hasattr(backend, 'V_next') else torch.empty_like(V)
         self.local_count = float(local_count)
         self.bytes = dict(reduce_scatter=V.numel() * 4, all_gather=V.numel() * V.element_size())
-        self._spans = {'reduce_scatter': [], 'all_gather': []}
+        # the first span (communicator set-up) and the latest 32: a long fit must not accumulate events without bound
+        self._spans = {'reduce_scatter': collections.deque(maxlen=33), 'all_gather': collections.deque(maxlen=33)}
+        self._first_span_kept = {'reduce_scatter': True, 'all_gather': True}
 
     def _timed(self, name, fn, t):
         if not t.is_cuda:
@@ -140,7 +144,10 @@ class DataParallelEpoch:
         a.record()
         fn()
         b.record()
-        self._spans[name].append((a, b))
+        q = self._spans[name]
+        if len(q) == q.maxlen:
+            self._first_span_kept[name] = False   # the set-up call has rotated out
+        q.append((a, b))
 
     def step(self):
         """Returns the global mean loss as a 0-d fp64 tensor (no host sync)."""
@@ -164,12 +171,17 @@ class DataParallelEpoch:
     def comm_report(self):
         """Mean milliseconds of the two collectives on this rank (events on the launch stream, so queueing behind the
         local passes is not included), their payloads, and the process group they ran on."""
-        def mean(spans):
-            v = [a.elapsed_time(b) for a, b in spans[1:]] or [a.elapsed_time(b) for a, b in spans]   # the first call builds the communicator
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()   # elapsed_time raises on events that have not completed
+
+        def mean(name):
+            spans = list(self._spans[name])
+            skip = 1 if self._first_span_kept[name] and len(spans) > 1 else 0   # the first call builds the communicator
+            v = [a.elapsed_time(b) for a, b in spans[skip:]]
             return sum(v) / len(v) if v else None
         return dict(backend=dist.get_backend(self.group), ranks=self.world,
-                    reduce_scatter_ms=mean(self._spans['reduce_scatter']), reduce_scatter_bytes=self.bytes['reduce_scatter'],
-                    all_gather_ms=mean(self._spans['all_gather']), all_gather_bytes=self.bytes['all_gather'],
+                    reduce_scatter_ms=mean('reduce_scatter'), reduce_scatter_bytes=self.bytes['reduce_scatter'],
+                    all_gather_ms=mean('all_gather'), all_gather_bytes=self.bytes['all_gather'],
                     note='per rank and epoch: reduce-scatter(sum) of the fp32 item gradient, all-gather of the updated item rows; '
                          'not overlapped with compute (a few ms against ~100 ms of local passes at C4)')
 
@@ -253,6 +265,9 @@ class ItemShardedEpoch:
     links only - every receiver gets it over ONE link, w / 153 GB/s; with every rank holding 1/world of the window all links
     of all GPUs carry w / world each, world times faster - the same reason the replicated path uses reduce-scatter + all-gather
     rather than reduce + broadcast.  The table crosses the fabric once per walk, overlapped with that walk's compute.
+    STATUS - design intent, UNMEASURED: the asynchronous branch has only run on a 1-rank nccl group (no peer, no real overlap)
+    and, host-staged and synchronous, under gloo; no run over RCCL with world > 1 has happened, so neither the overlap nor
+    the link arithmetic above has been observed on hardware.
     ``backend``: V_own(), two_phase, scores_window(t, Vwin), between(), grads_window(t, Vwin, out), finish_users(),
     adam_rows(W, G) - teamoflow_amd._windowed.WindowedHipBackend on the GPU, the NumPy oracle in tests/test_dist_cpu.py."""
 

@@ -257,8 +257,8 @@ class MatrixFactorization:
         self.item_trainable = [self.item_embedding]
 
     def _fit_generic(self, epochs, user_features, item_features, interactions, lr, U, V):
-        self._sharded_epoch = None
         """The reference's dense loop (:128-187) over arbitrary plug-ins, differentiated by autograd."""
+        self._sharded_epoch = None
         dev = U.device
         interactions = interactions.to(dev)
         idx = interactions.indices
@@ -546,6 +546,9 @@ def _save_to_disk(model, path, include_samples=True, allow_pickle=False):
 
 def _load_from_disk(cls, path, device=None, allow_pickle=False):
     blob = torch.load(path, map_location='cpu', weights_only=not allow_pickle)
+    if blob.get('format') == 'teamoflow_amd.mf/1':
+        raise ValueError(f'{path}: saved by an older version of this package (format /1, pickled plug-ins); load it with that '
+                         'version and save it again - the current format /2 stores plain data only')
     if blob.get('format') != 'teamoflow_amd.mf/2':
         raise ValueError(f'{path}: not a teamoflow_amd model file')
     cfg = {k: (_decode_plugin(v) if k in _PLUGIN_KEYS else v) for k, v in blob['config'].items()}

@@ -28,19 +28,41 @@ def rel_err(x, ref):
     return float(np.abs(x - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
+def report_slack(**fields):
+    """One line per check into gpurun_out/slack_report.jsonl (merged back from the GPU box) and onto stdout (pytest -s): how
+    many hinge terms sat on the kink, how many elements needed the slack they grant, and how much of it was consumed - a
+    regression hiding inside the slack shows up as these numbers growing."""
+    import json
+    line = json.dumps(fields)
+    print('[slack]', line)
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'slack_report.jsonl'), 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
 def assert_close_with_slack(x, ref, slack=None, rtol=1e-5, what=''):
     """max_i (|x_i - ref_i| - slack_i) <= rtol * max|ref|: norm-wise agreement except for what the boundary hinge terms
-    may legitimately move (oracle.sparse_ref.wmrb_slack / oracle_wmrb_boundary_slack)."""
+    may legitimately move (oracle.sparse_ref.wmrb_slack / oracle_wmrb_boundary_slack).
+    -> dict(n_over, max_consumed): the number of elements that only pass BECAUSE of their slack, and the largest share of
+    its slack any of them used."""
     x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
     if not x.size:
-        return
+        return dict(n_over=0, max_consumed=0.0)
     sl = np.zeros_like(ref) if slack is None else 1.0001 * np.asarray(slack, np.float64)
-    d = np.abs(x - ref) - sl
+    d0 = np.abs(x - ref)
+    d = d0 - sl
     lim = rtol * max(float(np.abs(ref).max()), 1e-30)
     if float(d.max()) > lim:
         i = np.unravel_index(int(d.argmax()), d.shape)
         raise AssertionError(f'{what}: {int((d > lim).sum())} of {d.size} elements differ by more than {lim:.3g} + slack; worst at {i}: '
                              f'got {x[i]!r}, reference {ref[i]!r}, slack {sl[i]!r}')
+    over = d0 > lim
+    consumed = float(((d0[over] - lim) / sl[over]).max()) if over.any() else 0.0
+    return dict(n_over=int(over.sum()), max_consumed=consumed)
 
 
 def step_bounds(W0, g_ref, lr, rtol=1e-5, slack=None):

@@ -127,13 +127,14 @@ def test_c5_shard_loss_and_reproducibility(c5):
 
 
 def test_c5_shard_fused_topk_on_trained_tables(c5):
-    """predict at the config-5 shape: fused bf16 top-10 of 512 users over the 1M-item catalog equals the stable
-    top-10 of their materialised fp32 scores (by value: fp32 re-computation of bf16 products may differ in the last bit)."""
+    """predict at the config-5 shape: fused bf16 top-10 of 256 users over the 1M-item catalog against
+    oracle.dense_ref.tf_top_k on a CPU fp32 matmul of the same bf16 rows (index for index where the oracle's values are
+    separated, by value in near-ties: tests/test_gpu_fullsize.py::check_topk_against_cpu_oracle)."""
     from teamoflow_amd import _ops
+    from test_gpu_fullsize import check_topk_against_cpu_oracle
     st, r = c5['st'], c5['r']
-    U, V = st.U_nxt[:512, :r], st.V_nxt[:, :r]
+    U, V = st.U_nxt[:256, :r], st.V_nxt[:, :r]
     vals, idx = _ops.predict_topk(U, V, 10, return_values=True)
-    scores = U.float() @ V.float().T
-    want = torch.sort(scores, dim=1, descending=True, stable=True)[0][:, :10]
-    assert rel_err(vals.cpu().numpy(), want.cpu().numpy()) < 1e-5
-    assert rel_err(torch.gather(scores, 1, idx.to(torch.int64)).cpu().numpy(), vals.cpu().numpy()) < 1e-5
+    # one near-sign Adam step from a global-L2-normalised start leaves factors of almost equal magnitude, i.e. many (near-)equal
+    # scores: no share of index-for-index rows is demanded here (the full-catalog test demands 90 % on random tables)
+    check_topk_against_cpu_oracle(U, V, vals, idx, 10, min_exact_rows=0.0)

@@ -19,7 +19,17 @@ def test_c_abi_from_a_compiled_caller():
     assert res.returncode == 0 and 'PASS' in out, out
 
 
-def test_compiled_caller_builds_against_the_header():
-    """CPU: the caller compiles and links against include/tmf.h + libtmf.so (hipcc cross-compiles without a GPU)."""
-    subprocess.run(['make', '-C', os.path.dirname(EXE)], check=True, stdout=subprocess.DEVNULL)
-    assert os.path.exists(EXE)
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+LIB = os.path.join(ROOT, 'teamoflow_amd', 'libtmf.so')
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='build test: needs hipcc')
+@pytest.mark.skipif(not os.path.exists(LIB), reason='build test: needs libtmf.so (built by __graft_entry__.build())')
+def test_compiled_caller_builds_against_the_header(tmp_path):
+    """CPU: the caller compiles and links against include/tmf.h + the EXISTING libtmf.so (hipcc cross-compiles without a GPU).
+    Built into a temporary directory: the test neither rebuilds the library nor touches the source tree."""
+    out = tmp_path / 'cabi_fit'
+    subprocess.run([HIPCC, '-O2', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'cabi', 'cabi_fit.cpp'),
+                    '-o', str(out), '-L' + os.path.dirname(LIB), '-ltmf', '-Wl,-rpath,' + os.path.dirname(LIB)],
+                   check=True, stdout=subprocess.DEVNULL)
+    assert out.exists()

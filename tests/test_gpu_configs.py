@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close_with_slack, assert_step, rel_err
+from conftest import assert_close_with_slack, assert_step, rel_err, report_slack
 from test_gpu_parity import check_one_step, fit_model, tm  # noqa: F401  (tm is a fixture)
 
 pytestmark = pytest.mark.gpu
@@ -46,9 +46,17 @@ def test_c3_full_size(tm, S_):  # noqa: F811
     def check_step(model, Ub, Vb, mean, t, tag):
         sl = C.wmrb_boundary_slack(Ub, Vb, plan, n, S_)
         assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
-        assert_close_with_slack(model._state.wplan.D_in_model_order().cpu().numpy(), t['D'], sl['D'], what=f'D {tag}')
+        sD = assert_close_with_slack(model._state.wplan.D_in_model_order().cpu().numpy(), t['D'], sl['D'], what=f'D {tag}')
         # a switch moves cnt_k by 1, i.e. delta_k by w_k
-        assert_close_with_slack(model._state.wplan.delta.cpu().numpy(), t['delta'], sl['delta'], what=f'delta {tag}')
+        sd = assert_close_with_slack(model._state.wplan.delta.cpu().numpy(), t['delta'], sl['delta'], what=f'delta {tag}')
+        # the slack is computed by the oracle that is being trusted: report how many terms sat on the kink and what the GPU
+        # result actually consumed of it, and bound both - every switched term moves ONE element of D and ONE of delta, so no
+        # more elements than boundary pairs may need slack at all
+        report_slack(test=f'c3_full_size S={S_} {tag}', hinge_terms=int(len(val)) * S_, boundary_pairs=int(sl['pairs']),
+                     D_elements_needing_slack=sD['n_over'], D_max_slack_consumed=sD['max_consumed'],
+                     delta_elements_needing_slack=sd['n_over'], delta_max_slack_consumed=sd['max_consumed'])
+        assert sD['n_over'] <= sl['pairs'] and sd['n_over'] <= sl['pairs'], (sD, sd, sl['pairs'])
+        assert sD['max_consumed'] <= 1.0 and sd['max_consumed'] <= 1.0
         assert_step(model.user_embedding.cpu().numpy(), Ub, t['gU'], lr, what=f'C3 U {tag}', slack=sl['gU'])
         assert_step(model.item_embedding.cpu().numpy(), Vb, t['gV'], lr, what=f'C3 V {tag}', slack=sl['gV'])
         return sl['pairs']

@@ -1,0 +1,63 @@
+"""The reference's MovieLens benchmark script (/root/reference/examples/benchmarking_ML.py:35-175) at the BASELINE shapes, on the
+GPU, through the public surface only: ratings DataFrame -> df_to_sparse_pipeline -> convert_to_tf_sparse -> an MSE model and a
+WMRB model (UniformInitializer, n_samples = n_items // 5, generate_sample=True) -> recall@10 / 30 / 50 on the train / test /
+"ratings >= 4" matrices.  examples/movielens_shape.py is that call sequence on a synthetic frame; here it is run with the oracle's
+start injected (FixedInitializer) and every recall it prints is compared with the oracle trained from the same split, the same
+start and the same negative table (BASELINE: recall within 1e-3; loss trajectories 1e-5 at the start)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, 'examples'))
+
+
+@pytest.mark.parametrize('shape,r,epochs', [('100k', 32, 40), ('1m', 64, 20)])
+def test_movielens_shape_example_against_the_oracle(shape, r, epochs):
+    import movielens_shape as ms
+    from oracle import datagen as G
+    from oracle import dense_ref as D
+    from oracle import sparse_c as C
+    from teamoflow_amd.mf.initializer_graphs import FixedInitializer
+    m, n, n_ratings = ms.SHAPES[shape]
+    start = dict(mse=(G.normal_init(m, r, 1), G.normal_init(n, r, 2)), wmrb=(G.uniform_init(m, r, 3), G.uniform_init(n, r, 4)))
+    out = ms.run(m, n, n_ratings, n_components=r, epochs=epochs, seed=0, verbose=False,
+                 initializers={k: (FixedInitializer(u), FixedInitializer(v)) for k, (u, v) in start.items()})
+    models, A = out['models'], {k: v.numpy() for k, v in out['A'].items()}
+    S = out['n_samples']
+    assert S == n // 5 and tuple(A['train'].shape) == (m, n)
+    assert 0.79 * n_ratings <= (A['train'] != 0).sum() <= 0.81 * n_ratings          # the pipeline's fixed 0.2 test share
+    R = np.asarray(models['wmrb'].random_ind.cpu() if hasattr(models['wmrb'].random_ind, 'cpu') else models['wmrb'].random_ind)
+    assert R.shape == (m, S) and all(len(set(row)) == S for row in R[:: max(1, m // 50)])   # utils.py:20: distinct per user
+    C.set_threads(min(16, os.cpu_count() or 1))
+
+    def oracle_fit(kind, inter, lr):
+        idx, val = inter.indices.cpu().numpy(), inter.values.cpu().numpy()
+        U, V = start[kind]
+        plan = C.Plan(idx, val, m, n, R if kind == 'wmrb' else None)
+        losses = []
+        for _ in range(epochs):
+            if kind == 'wmrb':
+                U, V, mean, _t = C.wmrb_epoch(U, V, plan, n, S, lr, want_grads=False)
+            else:
+                U, V, mean, _t = C.mse_epoch(U, V, plan, lr, want_grads=False)
+            losses.append(mean)
+        return U, V, np.array(losses)
+
+    ref = {'mse': oracle_fit('mse', out['train'], 1e-3), 'wmrb': oracle_fit('wmrb', out['train_4plus'], 0.1)}
+    for kind, model in models.items():
+        U, V, losses = ref[kind]
+        got = np.array(model.loss_history_)
+        assert rel_err(got[:5], losses[:5]) < 1e-5, (kind, got[:5], losses[:5])
+        assert rel_err(got, losses) < 2e-3, (kind, rel_err(got, losses))
+        assert got[-1] < got[0]
+    for (kind, split, k), got in out['recalls'].items():
+        U, V, _ = ref[kind]
+        want = float(D.recall_at_k_dense(U, V, A[split], k).mean())
+        assert abs(got - want) <= 1e-3, (kind, split, k, got, want)
+    # the ranking model beats the rating model on the held-out >= 4 ratings, as the reference's README reports for this script
+    assert out['recalls'][('wmrb', 'test_4plus', 10)] > out['recalls'][('mse', 'test_4plus', 10)]

@@ -169,11 +169,45 @@ def test_full_size_mse_sampled_rows(c4):
     assert abs(float(loss[0]) - ref) <= 1e-5 * ref
 
 
+def oracle_topk(scores_cpu, k):
+    """oracle.dense_ref.tf_top_k (tf.math.top_k: descending, equal values lower index first) of every row of a wide fp32 CPU
+    matrix without sorting the million columns: the candidates of a row are the columns >= its (k+1)-th largest value, in
+    ascending column order, and tf_top_k ranks those."""
+    from oracle import dense_ref as D
+    kth = torch.topk(scores_cpu, k + 1, dim=1).values[:, -1]
+    vals, idx = [], []
+    for i in range(scores_cpu.shape[0]):
+        cand = torch.nonzero(scores_cpu[i] >= kth[i]).flatten()          # ascending column order
+        v, p = D.tf_top_k(scores_cpu[i, cand], k)
+        vals.append(v)
+        idx.append(cand[p])
+    return torch.stack(vals), torch.stack(idx)
+
+
+def check_topk_against_cpu_oracle(U, V, vals, idx, k, min_exact_rows=0.9):
+    """Fused top-k of the GPU against the oracle's ranking of a CPU fp32 matmul of the same rows.  The CPU BLAS sums the
+    r products in another order than the MFMA chain, so scores differ in the last bits: rows whose top k+1 oracle values are
+    separated by more than 1e-5 (relative) must match index for index; in the others (near-ties) the engine's picks must
+    carry the oracle's values."""
+    S = U.float().cpu() @ V.float().cpu().T
+    want_v, want_i = oracle_topk(S, k + 1)
+    gaps = (want_v[:, :-1] - want_v[:, 1:]) / want_v[:, :1].abs().clamp_min(1e-30)
+    clear = (gaps > 1e-5).all(dim=1)
+    got_i = idx.cpu().to(torch.int64)
+    assert float(clear.float().mean()) >= min_exact_rows, float(clear.float().mean())
+    assert torch.equal(got_i[clear], want_i[clear, :k])
+    picked = torch.gather(S, 1, got_i)
+    assert rel_err(picked.numpy(), want_v[:, :k].numpy()) < 1e-5
+    assert rel_err(vals.cpu().numpy(), picked.numpy()) < 1e-5
+    return S
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-def test_full_catalog_fused_topk_matches_materialised_scores(dtype):
+def test_full_catalog_fused_topk_matches_the_cpu_oracle(dtype):
     """predict at catalog scale (1,000,003 items - a ragged last tile, 512 MB of V, byte offsets up to 2^29 in the
-    kernel's buffer loads): the fused top-k of 300 users equals the stable top-k of the materialised score rows, and
-    the first / last items win when they should (planted maxima at both ends of the catalog)."""
+    kernel's buffer loads): the fused top-k of 300 users against oracle.dense_ref.tf_top_k on a CPU fp32 matmul of the same
+    rows (not against another kernel of this library), and the first / last items win when they should (planted maxima at
+    both ends of the catalog, an exact tie in the ragged tile)."""
     from teamoflow_amd import _ops
     dev = torch.device('cuda', 0)
     g = torch.Generator(device=dev).manual_seed(5)
@@ -186,13 +220,7 @@ def test_full_catalog_fused_topk_matches_materialised_scores(dtype):
     if dtype == 'bf16':
         U, V = U.to(torch.bfloat16), V.to(torch.bfloat16)
     vals, idx = _ops.predict_topk(U, V, 10, return_values=True)
-    scores = U.float() @ V.float().T if dtype == 'bf16' else _ops.predict_gemm(U, V)
-    want = _ops.topk_stable(scores, 10)
-    if dtype == 'f32':
-        assert torch.equal(idx, want)
-    else:   # fp32 re-computation of bf16 products may differ in the last bit: compare by value, ties aside
-        got_v = torch.gather(scores, 1, idx.to(torch.int64))
-        want_v = torch.gather(scores, 1, want.to(torch.int64))
-        assert rel_err(got_v.cpu().numpy(), want_v.cpu().numpy()) < 1e-5
+    check_topk_against_cpu_oracle(U, V, vals, idx, 10)
     assert int(idx[0, 0]) == 0 and idx[1, :2].tolist() == [n - 2, n - 1]
-    assert rel_err(vals.cpu().numpy(), torch.gather(scores, 1, idx.to(torch.int64)).cpu().numpy()) < 1e-5
+    if dtype == 'f32':   # and the library's own two-kernel path agrees bit for bit (same fmaf chain)
+        assert torch.equal(idx, _ops.topk_stable(_ops.predict_gemm(U, V), 10))

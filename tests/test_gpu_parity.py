@@ -260,18 +260,22 @@ def test_wmrb_user_chunked_item_lists(tm, golden, monkeypatch):
     assert rel_err(chunked.loss_history_, base.loss_history_) < 1e-6
 
 
-@pytest.mark.parametrize('slices', ['2', '5', '64'])
-def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices):
+@pytest.mark.parametrize('slices,xcd', [('2', '0'), ('5', '0'), ('64', '0'), ('5', '1'), ('13', '1'), ('64', '1')])
+def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, xcd):
     """TMF_ITEM_SLICES > 1: the sliced user pass (scores / hinge / gradU / finish) instead of the fused kernel;
-    also with per-slice gradU launches."""
+    also with per-slice gradU launches, and in XCD-major block order (every XCD its own slice; gradU then in rounds of
+    eight slices, one layer each, when the layers do not fit)."""
     monkeypatch.setenv('TMF_ITEM_SLICES', slices)
-    if slices == '5':
-        monkeypatch.setattr(tm.engine, 'PART_BUDGET', 0)  # memory-light gradU: one launch per slice
+    monkeypatch.setenv('TMF_SLICE_XCD', xcd)
+    if slices in ('5', '13'):
+        monkeypatch.setattr(tm.engine, 'PART_BUDGET', 0)  # memory-light gradU: one launch per slice / per round of eight
     for name in ('wmrb_small', 'wmrb_mixed'):
         g = golden(name)
         model, t = check_one_step(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, float(g['lr']), 'wmrb',
                                   g['R'], int(g['n_items']), int(g['n_samples']), fixture=(g['U_1'], g['V_1']))
-        assert model._state.wplan.n_slices == int(slices)
+        assert model._state.wplan.n_slices == int(slices) and model._state.wplan.xcd_major == (xcd == '1')
+        if slices in ('5', '13'):
+            assert model._state.gradu_launches == (3 if xcd == '1' else 1)
         assert rel_err(model._state.wplan.D_in_model_order().cpu().numpy(), t['D']) < 1e-5
     g = golden('wmrb_small')
     sliced = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 25, 0.1, 'wmrb', g['R'], 100, 50)

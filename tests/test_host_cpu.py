@@ -166,6 +166,26 @@ def test_reference_style_imports_and_surface():
     assert m2.n_components == 7
 
 
+def test_import_root_of_the_reference_tests():
+    """The import lines of the reference's own tests (/root/reference/test/test_loss.py:5-7, test_utils.py:5,
+    test_predict.py:5-8, test_embedding.py, test_initializer.py) resolve to this package, star-imports included."""
+    ns = {}
+    for line in ('from src.teamoflow.mf.loss_graphs import *',
+                 'from src.teamoflow.mf.utils import *',
+                 'from src.teamoflow.mf.predict_graphs import *',
+                 'from src.teamoflow.mf.embedding_graphs import *',
+                 'from src.teamoflow.mf.initializer_graphs import *',
+                 'from src.teamoflow.mf.utils import generate_random_interaction',
+                 'from src.teamoflow.mf.matrix_factorization import MatrixFactorization',
+                 'import src.teamoflow.mf.input_utils'):
+        exec(line, ns)
+    import teamoflow_amd.mf.matrix_factorization as impl
+    assert ns['MatrixFactorization'] is impl.MatrixFactorization
+    for name in ('MSELoss', 'WMRBLoss', 'KLDivergenceLoss', 'LinearEmbedding', 'BiasedLinearEmbedding', 'ReLUEmbedding',
+                 'NormalInitializer', 'UniformInitializer', 'random_sampler', 'gather_matrix_indices', 'generate_random_interaction'):
+        assert name in ns, name
+
+
 def test_generic_path_matches_oracle_on_cpu(golden):
     """Non-fast-path plug-ins (here: a dense non-identity feature matrix) train through the generic
     autograd loop; with identity features given densely AND a subclassed loss it must equal the oracle."""
