@@ -22,6 +22,15 @@ def random_sampler_device(n_items, n_users, n_samples, seed=0, device=None, rows
     device = default_device() if device is None else torch.device(device)
     gen = torch.Generator(device=device).manual_seed(seed)
     out = torch.empty(n_users, n_samples, dtype=torch.int32, device=device)
+    if 2 * n_samples > n_items:
+        # most of the catalog per row: rejection would take coupon-collector time - the first n_samples entries of a random
+        # permutation instead (argsort of uniform keys), in blocks of at most 2^26 keys
+        step = max(1, (1 << 26) // n_items)
+        for r0 in range(0, n_users, step):
+            rows = min(step, n_users - r0)
+            keys = torch.rand(rows, n_items, device=device, generator=gen)
+            out[r0:r0 + rows] = torch.argsort(keys, dim=1)[:, :n_samples].to(torch.int32)
+        return out
     for r0 in range(0, n_users, rows_per_block):
         rows = min(rows_per_block, n_users - r0)
         blk = torch.randint(0, n_items, (rows, n_samples), device=device, generator=gen, dtype=torch.int32)

@@ -184,18 +184,20 @@ def oracle_topk(scores_cpu, k):
     return torch.stack(vals), torch.stack(idx)
 
 
-def check_topk_against_cpu_oracle(U, V, vals, idx, k, min_exact_rows=0.9):
+def check_topk_against_cpu_oracle(U, V, vals, idx, k, min_identical_rows=0.97):
     """Fused top-k of the GPU against the oracle's ranking of a CPU fp32 matmul of the same rows.  The CPU BLAS sums the
     r products in another order than the MFMA chain, so scores differ in the last bits: rows whose top k+1 oracle values are
-    separated by more than 1e-5 (relative) must match index for index; in the others (near-ties) the engine's picks must
-    carry the oracle's values."""
+    separated by more than 1e-5 (relative) MUST match index for index; in the others (near-ties) the engine's picks must
+    carry the oracle's values, and over all rows at least `min_identical_rows` are index-identical anyway."""
     S = U.float().cpu() @ V.float().cpu().T
     want_v, want_i = oracle_topk(S, k + 1)
     gaps = (want_v[:, :-1] - want_v[:, 1:]) / want_v[:, :1].abs().clamp_min(1e-30)
     clear = (gaps > 1e-5).all(dim=1)
     got_i = idx.cpu().to(torch.int64)
-    assert float(clear.float().mean()) >= min_exact_rows, float(clear.float().mean())
+    assert bool(clear.any())
     assert torch.equal(got_i[clear], want_i[clear, :k])
+    identical = float((got_i == want_i[:, :k]).all(dim=1).float().mean())
+    assert identical >= min_identical_rows, (identical, float(clear.float().mean()))
     picked = torch.gather(S, 1, got_i)
     assert rel_err(picked.numpy(), want_v[:, :k].numpy()) < 1e-5
     assert rel_err(vals.cpu().numpy(), picked.numpy()) < 1e-5

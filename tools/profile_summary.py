@@ -49,6 +49,18 @@ for kind, cn in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         d[cn + '_KB_mean_per_launch'] = sum(v) / len(v)
         d['launches_' + cn] = len(v)
         d.update(meta[k])
+tcc = glob.glob(f'{src}/pmc_tcc/*/*_counter_collection.csv')
+if tcc:   # L2 hit rate per kernel: TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), summed over the launches
+    hm = collections.defaultdict(lambda: [0.0, 0.0])
+    for r in csv.DictReader(open(tcc[0])):
+        name = r['Kernel_Name']
+        if name.startswith('_ZN3tmf'):
+            name = demangle(name)
+        if 'tmf::' in name and r['Counter_Name'] in ('TCC_HIT_sum', 'TCC_MISS_sum'):
+            hm[name.split('(')[0].replace('void ', '')][r['Counter_Name'] == 'TCC_MISS_sum'] += float(r['Counter_Value'])
+    for k, (h, mi) in hm.items():
+        if h + mi > 0:
+            out.setdefault(k, {}).update(TCC_HIT_sum=h, TCC_MISS_sum=mi, l2_hit_rate=h / (h + mi))
 for k, d in list(out.items()):
     f, w = d.get('FETCH_SIZE_KB_mean_per_launch', 0), d.get('WRITE_SIZE_KB_mean_per_launch', 0)
     d['hbm_traffic_bytes_per_launch_corrected'] = 2 * f * 1024 + w * 1024
@@ -59,4 +71,5 @@ out['_note'] = ('traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024: on gfx950 FETCH_
                 'coalesced reads (MI355X_MICROARCH.md, HBM section); FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes')
 json.dump(out, open(os.path.join(dst, f'{tag}_pmc.json'), 'w'), indent=1)
 print(open(os.path.join(dst, f'{tag}_kernel_stats.csv')).read()[:1500])
-print(json.dumps({k: v.get('hbm_traffic_bytes_per_launch_corrected') for k, v in out.items() if not k.startswith('_')}, indent=1))
+print(json.dumps({k: dict(traffic_GB=round(v.get('hbm_traffic_bytes_per_launch_corrected', 0) / 1e9, 2), l2_hit_rate=v.get('l2_hit_rate'))
+                  for k, v in out.items() if not k.startswith('_')}, indent=1))
