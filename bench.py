@@ -35,6 +35,7 @@ from teamoflow_amd.mf.utils import random_sampler_device  # noqa: E402
 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; per-XCD L2 aggregate ~34.5 TB/s; Infinity Cache 256 MiB
 HBM_PEAK, L2_PEAK, MALL_BYTES = 8.0e12, 34.5e12, 256 << 20
 L2_GATHER_MEASURED = (16.8e12, 18.8e12)  # the guide's measured chip-wide rate of L2-resident row gathers
+HBM_COPY_MEASURED = 6.29e12                # the guide's measured float4 copy from HBM (79 % of the 8 TB/s spec)
 
 
 def log(*a):
@@ -157,22 +158,35 @@ def roofline_report(models, prof, pmc=None):
         if k['gather']:
             e.update(rows_gathered=k['rows'], gather_bytes=k['gather'], gather_rate_GBps=k['gather'] / t / 1e9,
                      l2_frac=k['gather'] / t / L2_PEAK)
+        meas = pmc.get(name) if pmc else None
         if k['roof'] == 'l2':
             e.update(bound='l2', achieved=e['gather_rate_GBps'], peak=L2_PEAK / 1e9, frac=e['l2_frac'])
+        elif k['roof'] == 'hbm' and meas is not None:
+            # HBM-bound kernel with counters of this code version: the fraction is MEASURED fabric bytes (L2 misses + writes,
+            # FETCH_SIZE / WRITE_SIZE) over the kernel's time against the 8 TB/s peak - not the byte model
+            rate = meas['bytes'] / t
+            e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=min(rate / HBM_PEAK, 1.0), frac_source='pmc',
+                     hbm_model_frac=e['hbm_frac'])
+            if rate > HBM_COPY_MEASURED:
+                e['note'] = (f"measured fabric rate {rate / 1e12:.2f} TB/s is above the {HBM_COPY_MEASURED / 1e12:.2f} TB/s the guide measures for a "
+                             f"float4 copy from HBM: FETCH_SIZE counts Infinity-Cache hits too, so part of it is served by the 256 MiB cache "
+                             f"(L2 hit rate {meas.get('l2_hit_rate')}); the HBM share cannot be separated with the exposed counters")
         elif k['roof'] == 'hbm' and e['hbm_frac'] > 1.0 and k['gather']:
-            # the no-reuse model (every gathered row of a table beyond the Infinity Cache comes from HBM) over-counts when the
-            # row popularity is skewed (power-law item ids): hot rows are re-served on chip.  Price the kernel on the L2 roof.
+            # no counters for this code version and the no-reuse model (every gathered row of a table beyond the Infinity Cache comes
+            # from HBM) exceeds the peak: rows are re-served on chip.  Price the kernel on the L2 roof and say so.
             e.update(bound='l2', achieved=e['gather_rate_GBps'], peak=L2_PEAK / 1e9, frac=e['l2_frac'],
-                     note=f"HBM model without reuse would give {e['hbm_frac']:.2f} of the HBM peak: popular rows are served on chip")
+                     note=f"UNVALIDATED byte model: without reuse it would give {e['hbm_frac']:.2f} of the HBM peak, so rows are served on chip; "
+                          "no PMC profile of this code version to say how many")
             e['hbm_frac'] = None
         elif k['roof'] == 'hbm':
-            e.update(bound='hbm', achieved=e['hbm_rate_GBps'], peak=HBM_PEAK / 1e9, frac=e['hbm_frac'])
+            e.update(bound='hbm', achieved=e['hbm_rate_GBps'], peak=HBM_PEAK / 1e9, frac=e['hbm_frac'], frac_source='byte model (no counters)')
         else:
             e.update(bound='issue', achieved=e['hbm_rate_GBps'], peak=HBM_PEAK / 1e9, frac=e['hbm_frac'],
                      note='instruction-issue / LDS-latency bound; the HBM figure only shows it is far from that roof')
-        if pmc and name in pmc:
-            e.update(traffic=pmc[name]['bytes'], hbm_traffic_frac=pmc[name]['bytes'] / t / HBM_PEAK,
-                     traffic_uncorrected=pmc[name]['bytes_uncorrected'])
+        if meas is not None:
+            e.update(traffic=meas['bytes'], hbm_traffic_frac=min(meas['bytes'] / t / HBM_PEAK, 1.0),
+                     traffic_uncorrected=meas['bytes_uncorrected'], traffic_rate_GBps=meas['bytes'] / t / 1e9,
+                     l2_hit_rate=meas.get('l2_hit_rate'))
         entries.append(e)
     entries.sort(key=lambda e: -e['ms'])
     return entries
@@ -181,8 +195,12 @@ def roofline_report(models, prof, pmc=None):
 # kernel symbol prefixes of the per-kernel timer names, for matching the committed PMC profile
 PMC_KERNELS = {'wmrb_scores': 'tmf::k_wmrb_scores3', 'wmrb_hinge': 'tmf::k_wmrb_hinge2', 'wmrb_gradu': 'tmf::k_wmrb_gradu3',
                'wmrb_finish': 'tmf::k_wmrb_finish', 'wmrb_item_pass': 'tmf::k_wsum_pass', 'wmrb_combine': 'tmf::k_combine_rows',
-               'wmrb_user_pass': 'tmf::k_wmrb_user'}
+               'wmrb_user_pass': 'tmf::k_wmrb_user',
+               # the two launches per epoch of one kernel, told apart by dispatch order in tools/profile_summary.py
+               'mse_user_pass': ('tmf::k_mse_pass', '[user pass]'), 'mse_item_pass': ('tmf::k_mse_pass', '[item pass]')}
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_c4_latest.json')
+PMC_LEG_FILES = {'c4_mse': os.path.join(ROOT, 'profiles', 'pmc_c4_mse_latest.json'),
+                 'c5_shard_bf16': os.path.join(ROOT, 'profiles', 'pmc_c5_latest.json')}
 
 
 def csrc_sha():
@@ -195,26 +213,28 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
+def pmc_traffic(path=None):
     """Fabric bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and WRITE_SIZE
-    in separate runs).  bench.py cannot collect counters itself; the workload is seeded, so the profile applies to this
+    in separate runs; TCC_HIT / TCC_MISS in a third -> l2_hit_rate).  bench.py cannot collect counters itself; the workload is seeded, so the profile applies to this
     run - but only when it was taken on THIS version of the kernels: the file carries the sha of csrc/ and is ignored on
     a mismatch.  FETCH_SIZE counts half the bytes of 16-byte-per-lane reads on gfx950 (MI355X_MICROARCH.md, HBM):
     `bytes` doubles it for the row-gather kernels (their traffic is 16-byte row loads), `bytes_uncorrected` does not."""
+    path = path or PMC_FILE
     try:
-        d = json.load(open(PMC_FILE))
+        d = json.load(open(path))
     except (OSError, ValueError):
         return None, 'no profile committed'
     if d.get('_csrc_sha') != csrc_sha():
         return None, f"profile is for csrc {d.get('_csrc_sha')}, this is {csrc_sha()}"
     out = {}
-    for name, prefix in PMC_KERNELS.items():
+    for name, pat in PMC_KERNELS.items():
+        prefix, suffix = pat if isinstance(pat, tuple) else (pat, '')
         for k, v in d.items():
-            if k.startswith(prefix) and 'FETCH_SIZE_KB_mean_per_launch' in v:
+            if k.startswith(prefix) and k.endswith(suffix) and 'FETCH_SIZE_KB_mean_per_launch' in v:
                 f, w = v['FETCH_SIZE_KB_mean_per_launch'] * 1024, v.get('WRITE_SIZE_KB_mean_per_launch', 0) * 1024
                 wide = name != 'wmrb_hinge'   # the hinge kernel reads 4 bytes per lane: correction not calibrated, left out
-                out[name] = dict(bytes=(2 * f if wide else f) + w, bytes_uncorrected=f + w)
-    return out, os.path.relpath(PMC_FILE, ROOT)
+                out[name] = dict(bytes=(2 * f if wide else f) + w, bytes_uncorrected=f + w, l2_hit_rate=v.get('l2_hit_rate'))
+    return out, os.path.relpath(path, ROOT)
 
 
 def host_cores():
@@ -440,14 +460,16 @@ def run_steps(wl, steps, warmup, dp=None, backend=None):
     return t1 - t0, t0 - tw, prof, loss_buf
 
 
-def hbm_leg(args, dev, name, m, n, nnz, r, S, loss, dtype, steps, warmup):
-    """A side leg on a workload whose factor tables really stream from HBM: same timed-region rules."""
+def hbm_leg(args, dev, name, m, n, nnz, r, S, loss, dtype, steps, warmup, pmc_key=None):
+    """A side leg on a workload whose factor tables really stream from HBM: same timed-region rules.
+    `traffic` per kernel = fabric bytes from the committed PMC passes of the same workload and code version (or absent)."""
     wl = Workload(args, m, n, nnz, r, S, loss, dtype, 0, 1, dev)
     elapsed, _, prof, loss_buf = run_steps(wl, steps, warmup)
     models = wl.models()
+    pmc, pmc_src = pmc_traffic(PMC_LEG_FILES[pmc_key]) if pmc_key else (None, None)
     out = dict(workload=wl.describe(name), interactions=wl.nnz, steps=steps, warmup=warmup, ms_per_step=elapsed / steps * 1e3,
                value=wl.nnz / (elapsed / steps), unit='interactions/s', dtype='f32' if dtype == 'f32' else 'bf16 storage / f32 arithmetic',
-               kernels=roofline_report(models, prof), prep_seconds=wl.prep_seconds,
+               kernels=roofline_report(models, prof, pmc), traffic_source=pmc_src, prep_seconds=wl.prep_seconds,
                epoch_hbm_bytes=sum(k['hbm'] for k in models.values()),
                epoch_hbm_frac=epoch_hbm_frac(models, elapsed / steps),
                hbm_gib_peak=torch.cuda.max_memory_allocated() / 2 ** 30)
@@ -833,9 +855,9 @@ def main():
         del wl
         torch.cuda.empty_cache()
         out['hbm_legs'] = dict(
-            c4_mse=hbm_leg(args, dev, 'C4 shape, MSE', 1_000_000, 100_000, 100_000_000, 128, 1024, 'mse', 'f32', 20, 5),
+            c4_mse=hbm_leg(args, dev, 'C4 shape, MSE', 1_000_000, 100_000, 100_000_000, 128, 1024, 'mse', 'f32', 20, 5, 'c4_mse'),
             c5_shard_bf16=hbm_leg(args, dev, 'config-5 shard (1/8 of 10M x 1M)', 1_250_000, 1_000_000, 125_000_000, 256, 1024, 'wmrb',
-                                  'bf16', 5, 2))
+                                  'bf16', 5, 2, 'c5_shard_bf16'))
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
     if dp_mode:

@@ -200,6 +200,21 @@ int tmf_wmrb_gradu3_f32(const tmf_slice_lists* lists, const float* D, const floa
                         int per_slice_launches, int n_components, void* stream);
 int tmf_wmrb_gradu3_bf16(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, float* part,
                          int per_slice_launches, int n_components, void* stream);
+/* Row-stationary form of gradu3 + finish in one kernel (speed only - same result up to the order of the fp32 sum over a
+ * user's slices, which is ascending here too): every lane group owns a few users, keeps their gradient rows in registers
+ * and walks all slices itself; U_out[u] = epilogue(sum_slice ...).  The users are launched in blocks of `users_per_launch`
+ * (all workgroups of a block resident together, so they walk the slices in loose lockstep and the slice stays in the L2s).
+ * For catalogs far beyond the L2s, where a (user, slice) range holds a handful of rows. */
+int tmf_wmrb_gradu4_supported(int n_components, int bf16);   /* rows of at least 8 lanes (r > 28 fp32, r > 56 bf16) */
+size_t tmf_wmrb_gradu4_workspace_bytes(int32_t n_users, int32_t n_slices, int32_t users_per_launch);
+/* workspace (optional, device memory): one int per (launch, slice), zeroed by the call; with it the workgroups of a launch
+ * rendezvous once per slice (bounded wait, speed only) so that they stay within two slices of each other. */
+int tmf_wmrb_gradu4_f32(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, const void* U_old,
+                        void* U_out, int n_components, int epi, tmf_adam adam, int32_t users_per_launch, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int tmf_wmrb_gradu4_bf16(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, const void* U_old,
+                         void* U_out, int n_components, int epi, tmf_adam adam, int32_t users_per_launch, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int tmf_wmrb_finish_f32(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,
                         int n_components, int epi, tmf_adam adam, void* stream);
 int tmf_wmrb_finish_bf16(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,

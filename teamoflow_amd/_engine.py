@@ -431,8 +431,15 @@ class TrainState:
         self.plan, self.wplan = plan, wplan
         need = dict(slab=max(plan.seg_u.n_slab, plan.seg_i.n_slab if plan.seg_i else 0, wplan.seg_e.n_slab if wplan else 0, 1) * self.ld,
                     loss_part=max(plan.seg_u.nseg, plan.n_users, 1))
+        self.row_stationary = False
         if wplan is not None and wplan.sliced:
             m, S = wplan.R.shape
+            self.row_stationary = (os.environ.get('TMF_ROW_STATIONARY') == '1'
+                                   and bool(_lib.load_library().tmf_wmrb_gradu4_supported(self.r, int(dtype is torch.bfloat16))))
+            self.users_per_launch = int(os.environ.get('TMF_G4_USERS', 32768))
+            if self.row_stationary:
+                nb = _lib.load_library().tmf_wmrb_gradu4_workspace_bytes(m, wplan.n_slices, self.users_per_launch)
+                self.g4_sync = torch.zeros(max(nb // 4, 1), dtype=torch.int32, device=dev)
             # gradU partials: one layer per slice, or (above PART_BUDGET bytes) a single layer summed by per-slice launches -
             # eight layers summed by per-round launches when the slices are walked XCD-major
             ns = wplan.n_slices
@@ -559,6 +566,12 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None, user_epi=_lib.EPI_ADAM, 
                                                                             _lib.ptr(st.pk), r, s))
     timed('wmrb_hinge', lambda: lib.tmf_wmrb_hinge2(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(st.pk), _lib.ptr(st.sp),
                                                     i32(m), i32(S), c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), s))
+    if st.row_stationary:
+        # gradU + finish in one row-stationary kernel (lane groups own users and walk the slices; no partial rows)
+        timed('wmrb_gradu', lambda: getattr(lib, 'tmf_wmrb_gradu4' + st.sfx)(
+            lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(st.V), _lib.ptr(st.U), _lib.ptr(st.U_nxt if U_out is None else U_out),
+            r, user_epi, adam, i32(st.users_per_launch), _lib.ptr(st.g4_sync), st.g4_sync.numel() * 4, s))
+        return
     timed('wmrb_gradu', lambda: getattr(lib, 'tmf_wmrb_gradu3' + st.sfx)(
         lists, _lib.ptr(w.D), _lib.ptr(w.delta), _lib.ptr(st.V), _lib.ptr(st.part),
         st.gradu_launches, r, s))

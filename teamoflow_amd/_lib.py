@@ -73,6 +73,9 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_scores3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_hinge2': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P]),
     'tmf_wmrb_gradu3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _I, _P]),
+    'tmf_wmrb_gradu4_supported': (_I, [_I, _I]),
+    'tmf_wmrb_gradu4_workspace_bytes': (_SZ, [_I32, _I32, _I32]),
+    'tmf_wmrb_gradu4_f32': (_I, [_SL, _P, _P, _P, _P, _P, _I, _I, Adam, _I32, _P, _SZ, _P]),
     'tmf_wmrb_finish_f32': (_I, [_P, _I32, _I32, _P, _P, _I, _I, Adam, _P]),
     'tmf_adam_fresh_rows_f32': (_I, [_P, _P, _L, _I, Adam, _P]),
     'tmf_adam_step': (Adam, [_F, _I]),
@@ -92,7 +95,7 @@ _BASE_SIGNATURES = {
 }
 
 SIGNATURES.update(_BASE_SIGNATURES)
-for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_gradu3', 'tmf_wmrb_finish'):
+for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_gradu3', 'tmf_wmrb_gradu4', 'tmf_wmrb_finish'):
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name + '_f32']
 
 _lib = None

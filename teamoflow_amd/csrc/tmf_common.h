@@ -24,6 +24,15 @@ int check_launch(const char* what);
         }                                  \
     } while (0)
 
+// A HIP launch carries its global size (blocks x threads) in 32 bits: beyond 2^32 work-items the grid is silently truncated
+// (found in round 3: 78125 user groups x 256 slices x 256 threads "ran" in a third of the time and skipped most of the work).
+inline bool launch_fits(uint64_t blocks, unsigned threads) {
+    return blocks > 0 && blocks < (1ull << 31) && blocks * threads < (1ull << 32);
+}
+#define TMF_REQUIRE_LAUNCH(blocks, threads, what)                                                                      \
+    TMF_REQUIRE(tmf::launch_fits((uint64_t)(blocks), (unsigned)(threads)), "%s: %llu blocks of %u threads exceed one launch", \
+                what, (unsigned long long)(blocks), (unsigned)(threads))
+
 // Kernels that ask for more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which applies to
 // the CURRENT device only: remember what was granted per device (one LdsGrant per kernel instance; a process may
 // drive several devices, and the call is cheap enough to repeat when two host threads race on a first use).

@@ -353,7 +353,6 @@ static int check_segments(const tmf_segments* s) {
     TMF_REQUIRE(s != nullptr, "segments is null");
     TMF_REQUIRE(s->nseg >= 0 && s->chunk > 0, "segments: nseg=%lld chunk=%d", (long long)s->nseg, s->chunk);
     TMF_REQUIRE(s->nseg == 0 || (s->rowptr && s->seg_row && s->seg_chunk && s->seg_slab), "segments: null array");
-    TMF_REQUIRE(s->nseg < ((int64_t)1 << 31) * kWavesPerBlock, "segments: too many segments");
     return TMF_OK;
 }
 
@@ -372,6 +371,7 @@ static int mse_pass_impl(const tmf_segments* seg, const int32_t* other, const fl
     const RowGeom geom = row_geom_of<T>(n_components);
     const SegView sv = view(seg);
     const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
+    TMF_REQUIRE_LAUNCH((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock, 64 * kWavesPerBlock, "mse_pass");
 #define CALL(G_, NV_)                                                                                          \
     hipLaunchKernelGGL((k_mse_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
                        sv, other, val, (const T*)X_old, (const T*)Y_old, X_out, slab, loss_part, epi, adam)
@@ -398,6 +398,7 @@ static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const
         if (!(env && env[0] == '0') && geom.G >= 16 && (forced || seg->nseg / (64 / geom.G) >= 16384)) {
             const int64_t per_block = (int64_t)kWavesPerBlock * (64 / geom.G);
             const unsigned pblocks = (unsigned)((seg->nseg + per_block - 1) / per_block);
+            TMF_REQUIRE_LAUNCH((seg->nseg + per_block - 1) / per_block, 64 * kWavesPerBlock, "wsum_pass");
 #define CALLPG(G_, NV_)                                                                                               \
     hipLaunchKernelGGL((k_wsum_pass_pg<G_, NV_, T>), dim3(pblocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
                        sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
@@ -407,6 +408,7 @@ static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const
         }
     }
     const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
+    TMF_REQUIRE_LAUNCH((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock, 64 * kWavesPerBlock, "wsum_pass");
 #define CALL(G_, NV_)                                                                                           \
     hipLaunchKernelGGL((k_wsum_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
                        sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
@@ -423,6 +425,7 @@ static int combine_rows_impl(const int32_t* long_rows, const int64_t* slab_beg, 
     TMF_REQUIRE(epi == TMF_EPI_GRAD || X_old, "combine_rows: X_old is null");
     const RowGeom geom = row_geom_of<T>(n_components);
     const unsigned blocks = (unsigned)((n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+    TMF_REQUIRE_LAUNCH((n_long + kWavesPerBlock - 1) / kWavesPerBlock, 64 * kWavesPerBlock, "combine_rows");
 #define CALL(G_, NV_)                                                                                              \
     hipLaunchKernelGGL((k_combine_rows<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
                        long_rows, slab_beg, n_long, slab, (const T*)X_old, X_out, epi, adam)

@@ -346,6 +346,7 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
     }
     static LdsGrant grant;  // per template instance
     if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_wmrb_user<G, NV, T>), lds, grant)) return rc;
+    TMF_REQUIRE_LAUNCH(n_users, kThreads, "wmrb_user_pass");
     hipLaunchKernelGGL((k_wmrb_user<G, NV, T>), dim3((unsigned)n_users), dim3(kThreads), lds, stream, rowptr, col,
                        val, R, (int)S, c, U_old, V_old, U_out, delta, D, loss_part, pos_part, epi, adam);
     return check_launch("tmf_wmrb_user_pass");
@@ -562,6 +563,187 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_gradu3(SliceLists a, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-stationary user gradient ("gradu4"): a lane group OWNS K users, keeps their gradient rows in registers and walks
+// ALL slices itself - no per-(user, slice) partial row, no finish kernel, no re-read of anything per visit.  Built for
+// catalogs far beyond the L2s, where a slice small enough for one L2 leaves a (user, slice) range a handful of rows and
+// the slice-major kernels above spend their time on the offsets -> ids -> rows round trips of every visit:
+//   * the slice offsets of a user are cached 32 slices at a time in one register per list (lane l holds slice base + l);
+//   * the ids and weights of slice sl + 1 are loaded (one entry per lane, both lists, K users) while slice sl is being
+//     gathered, and handed over through a double-buffered LDS stage - a row gather only ever waits for LDS;
+//   * a launch covers a block of users small enough for all its workgroups to be resident together, so they walk the
+//     slices in loose lockstep (one workgroup barrier per slice keeps the lane groups of a workgroup together) and the
+//     slice being gathered from stays in the L2s; the host launches block after block.
+// Sum order of a user's row: slices ascending, negatives then interactions inside a slice, entries ascending - ONE running
+// fp32 sum (gradu3 + finish add per-slice partial sums), so the two forms agree to rounding, not to the bit.
+// ---------------------------------------------------------------------------------------------
+// Soft rendezvous of the workgroups of a launch, once per slice (speed only - no data is handed over, so no fences):
+// "I have finished slice i" is one relaxed agent-scope add; before going on, wait until EVERY workgroup has finished slice
+// i - lag, so the workgroups of a launch are spread over at most lag + 1 slices and those stay in the L2s.  The wait is
+// BOUNDED: if a workgroup of the launch is not resident (or the counters are stale) the others give up after ~50 us and run
+// on, unsynchronised but correct - a launch can never hang on it.
+// One counter per (slice, XCD lane): blocks b and b + 8 share an XCD under the observed round-robin placement, and a slice has
+// to stay resident per XCD L2 only - so a workgroup meets just the workgroups of its own lane (an eighth of the arrivals per
+// counter, each on a 64-byte line of its own).
+constexpr int kSyncStride = 16;   // ints between counters
+__device__ __forceinline__ void slice_rendezvous(int* sync, int i, int lag, int n_groups) {
+    const int x = blockIdx.x & 7;
+    const int mine = (n_groups - x + 7) / 8;   // workgroups of this lane
+    __hip_atomic_fetch_add(sync + (i * 8 + x) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int need = i - lag;
+    if (need < 0) return;
+    for (int spin = 0; spin < 256; ++spin) {
+        if (__hip_atomic_load(sync + (need * 8 + x) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+template <int G>
+struct Stage4 {
+    static constexpr int cap = G < 16 ? G : 16;   // entries of one (user, slice) visit staged per step; longer visits finish inline
+};
+
+template <int G>
+__device__ __forceinline__ int group_read(int v, int idx) {   // v of lane `idx` of this lane group
+    return __shfl(v, (threadIdx.x & 63 & ~(G - 1)) + idx, 64);
+}
+
+template <int G, int NV, typename T, int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wmrb_gradu4(   // two workgroups per CU: 4 waves per SIMD, <= 128 VGPRs
+    SliceLists a, const T* __restrict__ V, const float* __restrict__ D,
+                                                          const float* __restrict__ delta, const T* __restrict__ U_old,
+                                                          void* __restrict__ U_out, int epi, tmf_adam adam, int64_t user_begin,
+                                                          int64_t user_end, int* __restrict__ sync, int lag) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NG = 64 / G, NGB = NG * WAVES, CAP = Stage4<G>::cap, WIN = G - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane & (G - 1), gid = wave * NG + lane / G;
+    int* stage = reinterpret_cast<int*>(smem_raw) + gid * (2 * K * 2 * CAP);   // [buffer][user][ids CAP | weights CAP]
+    V = window_base<G, NV, T>(V, a.item_base);
+    const int64_t u0 = user_begin + ((int64_t)blockIdx.x * NGB + gid) * K;
+    const int sl_end = a.sl0 + a.nsl;
+    Frag<NV> acc[K];
+    int us[K], rb[K];          // first negative / first interaction of the user (interactions + n_users * n_samples < 2^31)
+    bool live[K];
+    int ocn[K], ocp[K];        // offsets cache: lane l = offset of slice base + l (negatives / interactions)
+    int c_tot[K];              // entries of the visit being gathered
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        zero<NV>(acc[k]);
+        live[k] = u0 + k < user_end;
+        const int64_t u = live[k] ? u0 + k : user_begin;
+        us[k] = (int)(u * (int64_t)a.S);
+        rb[k] = (int)a.rowptr[u];
+    }
+    int base = a.sl0;
+    auto refill = [&](int b) {
+        base = b;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t u = live[k] ? u0 + k : user_begin;
+            const int64_t o = u * (a.n_slices + 1) + ((b + g <= a.n_slices) ? b + g : a.n_slices);
+            ocn[k] = a.off[o];
+            ocp[k] = a.poff[o];
+        }
+    };
+    // entry e (= this lane) of the visit (user k, slice sl): its id and weight, or the resident row with weight 0
+    int n_tot[K], n_id[K];
+    float n_w[K];
+    auto fetch = [&](int sl) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int nb = group_read<G>(ocn[k], sl - base), ne = group_read<G>(ocn[k], sl + 1 - base);
+            const int pb = group_read<G>(ocp[k], sl - base), pe = group_read<G>(ocp[k], sl + 1 - base);
+            const int cn = live[k] ? ne - nb : 0;
+            n_tot[k] = live[k] ? cn + (pe - pb) : 0;
+            const bool neg = g < cn, any = g < n_tot[k] && g < CAP;
+            const int at = neg ? us[k] + nb + g : rb[k] + pb + (g - cn);
+            n_id[k] = any ? (neg ? a.R : a.col)[at] : a.item_base;
+            n_w[k] = any ? (neg ? D : delta)[at] : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int* ids = stage + (buf * K + k) * 2 * CAP;
+            if (g < CAP) {
+                ids[g] = n_id[k];
+                reinterpret_cast<float*>(ids + CAP)[g] = n_w[k];
+            }
+            c_tot[k] = n_tot[k];
+        }
+        wave_lds_sync();
+    };
+    refill(a.sl0);
+    fetch(a.sl0);
+    commit(0);
+    for (int sl = a.sl0; sl < sl_end; ++sl) {
+        const int buf = (sl - a.sl0) & 1;
+        const bool more = sl + 1 < sl_end;
+        if (more) {
+            if (sl + 2 - base > WIN) refill(sl + 1);
+            fetch(sl + 1);   // in flight while this slice's rows are gathered
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int* ids = stage + (buf * K + k) * 2 * CAP;
+            const float* ws = reinterpret_cast<const float*>(ids + CAP);
+            const int cnt = c_tot[k] < CAP ? c_tot[k] : CAP;
+            for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
+                static_assert((kUnrollW == 4 && CAP % 4 == 0) || CAP < 4, "vector LDS reads assume four entries per step");
+                Raw<NV, T> raw[kUnrollW];
+                float d[kUnrollW];
+                int idv[kUnrollW];
+                if constexpr (CAP >= 4) {
+                    const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);
+                    const float4 w4 = *reinterpret_cast<const float4*>(ws + e0);
+                    idv[0] = id4.x; idv[1] = id4.y; idv[2] = id4.z; idv[3] = id4.w;
+                    d[0] = w4.x; d[1] = w4.y; d[2] = w4.z; d[3] = w4.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < kUnrollW; ++t) {
+                        idv[t] = (e0 + t < CAP) ? ids[e0 + t] : a.item_base;
+                        d[t] = (e0 + t < CAP) ? ws[e0 + t] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) {
+                    const bool want = e0 + t < cnt && d[t] != 0.f;   // slots past cnt hold the resident row with weight 0
+                    if (!want) d[t] = 0.f;
+                    load_raw<G, NV>(raw[t], V, want ? idv[t] : a.item_base, g);
+                }
+#pragma unroll
+                for (int t = 0; t < kUnrollW; ++t) {
+                    Frag<NV> y;
+                    to_frag<NV>(y, raw[t]);
+                    axpy<NV>(acc[k], d[t], y);
+                }
+            }
+            // a visit longer than the stage (more than CAP entries of ONE user in ONE slice): the rest straight from memory
+            if (c_tot[k] > CAP) {
+                const int64_t o = (u0 + k) * (a.n_slices + 1) + sl;
+                const int nb = a.off[o], cn = a.off[o + 1] - nb, pb = a.poff[o];
+                for (int e = CAP; e < c_tot[k]; ++e) {
+                    const bool neg = e < cn;
+                    const int at = neg ? us[k] + nb + e : rb[k] + pb + (e - cn);
+                    const float w = (neg ? D : delta)[at];
+                    if (w != 0.f) {
+                        Frag<NV> y;
+                        load_row<G, NV>(y, V, (neg ? a.R : a.col)[at], g);
+                        axpy<NV>(acc[k], w, y);
+                    }
+                }
+            }
+        }
+        if (more) commit(buf ^ 1);
+        if (sync != nullptr && tid == 0) slice_rendezvous(sync, sl - a.sl0, lag, (int)gridDim.x);
+        __syncthreads();   // lockstep of the workgroup's lane groups (the other buffer is private to this wave: no hazard)
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (live[k]) row_epilogue<G, NV, T>(acc[k], U_old, U_out, u0 + k, g, epi, adam);
+}
+
 // `part` and `U_out` are NOT restrict-qualified: with TMF_EPI_GRAD the caller may sum the layers in place (U_out == part,
 // include/tmf.h) - every lane loads all layers of its row before it stores the row.
 template <int G, int NV, typename T>
@@ -604,6 +786,11 @@ static int wmrb_user_pass_impl(const int64_t* rowptr, const int32_t* col, const 
     return TMF_OK;
 }
 
+extern "C" int tmf_wmrb_gradu4_supported(int n_components, int bf16) {
+    const RowGeom geom = bf16 ? row_geom_bf16(n_components) : row_geom(n_components);
+    return geom.ld != 0 && geom.G >= 8;
+}
+
 extern "C" int tmf_wmrb_user_pass_fits(int32_t S, int n_components) {
     const RowGeom geom = row_geom(n_components);
     return geom.ld != 0 && S > 0 && wmrb_user_lds(S, geom.ld) <= 160 * 1024;
@@ -642,14 +829,11 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
         if (v >= 16 && v <= 1024 && (v & (v - 1)) == 0) upg = v;
     }
     const int64_t groups = ((int64_t)l->n_users + upg - 1) / upg;
-    TMF_REQUIRE(groups * l->n_slices < ((int64_t)1 << 31), "%s: grid too large", what);
     const int sl0 = l->slice_begin, nsl = l->slice_count > 0 ? l->slice_count : l->n_slices - sl0;
     TMF_REQUIRE(sl0 >= 0 && nsl > 0 && sl0 + nsl <= l->n_slices && l->item_base >= 0, "%s: window [%d, +%d) of %d slices, item_base=%d",
                 what, sl0, l->slice_count, l->n_slices, l->item_base);
     int xcd = l->xcd_major != 0;
     if (const char* env = getenv("TMF_SLICE_XCD")) xcd = env[0] == '1';   // A/B runs
-    const int rounds = (nsl + 7) / 8;
-    TMF_REQUIRE(!xcd || groups * 8 * rounds < ((int64_t)1 << 31), "%s: grid too large", what);
     a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups,
                    upg, sl0, nsl, l->item_base, xcd};
     return TMF_OK;
@@ -684,15 +868,26 @@ static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const 
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(U && V && sp && (p || lists->col == nullptr), "wmrb_scores3: null pointer");
     const size_t lds = slice_lds(geom, waves);
+    // one launch carries < 2^32 work-items: many slices x many user groups go out in several launches of whole slices
+    // (XCD-major: whole rounds of eight)
+    const int unit = a.xcd ? 8 : 1;
+    const int64_t per_unit = a.n_groups * unit * 64 * waves;
+    const int max_units = (int)((((int64_t)1 << 32) - 1) / per_unit);
+    TMF_REQUIRE(max_units >= 1, "wmrb_scores3: %lld user groups exceed one launch", (long long)a.n_groups);
+    const int first = a.sl0, last = a.sl0 + a.nsl;
+    for (int s0 = first; s0 < last; s0 += max_units * unit) {
+        a.sl0 = s0;
+        a.nsl = (last - s0 < max_units * unit) ? last - s0 : max_units * unit;
 #define CALLW(G_, NV_, W_)                                                                                             \
     hipLaunchKernelGGL((k_wmrb_scores3<G_, NV_, T, W_>), dim3(slice_grid(a)), dim3(64 * W_), lds, \
                        (hipStream_t)stream, a, (const T*)U, (const T*)V, sp, p)
 #define CALL4(G_, NV_) CALLW(G_, NV_, 4)
 #define CALL8(G_, NV_) CALLW(G_, NV_, 8)
-    if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
+        if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
 #undef CALL4
 #undef CALL8
 #undef CALLW
+    }
     return check_launch("tmf_wmrb_scores3");
 }
 
@@ -707,6 +902,7 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
     TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
     const size_t lds = slice_lds(geom, waves);
     TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 3, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
+    TMF_REQUIRE_LAUNCH(a.n_groups * 8, 64 * waves, "wmrb_gradu3");
     if (per_slice_launches == 3) {   // rounds of eight slices, one layer per XCD lane (see k_wmrb_gradu3)
         for (int sl = a.sl0; sl < a.sl0 + a.nsl; sl += 8) {
             const int accumulate = (sl == a.sl0) ? 3 : 4;
@@ -737,16 +933,88 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
         }
         return check_launch("tmf_wmrb_gradu3");
     }
+    // several launches of whole slices when one would exceed 2^32 work-items (see wmrb_scores3_impl)
+    const int unit = a.xcd ? 8 : 1;
+    const int64_t per_unit = a.n_groups * unit * 64 * waves;
+    const int max_units = (int)((((int64_t)1 << 32) - 1) / per_unit);
+    TMF_REQUIRE(max_units >= 1, "wmrb_gradu3: %lld user groups exceed one launch", (long long)a.n_groups);
+    const int first = a.sl0, last = a.sl0 + a.nsl;
+    for (int s0 = first; s0 < last; s0 += max_units * unit) {
+        a.sl0 = s0;
+        a.nsl = (last - s0 < max_units * unit) ? last - s0 : max_units * unit;
 #define CALLW(G_, NV_, W_)                                                                                   \
     hipLaunchKernelGGL((k_wmrb_gradu3<G_, NV_, T, W_>), dim3(slice_grid(a)), dim3(64 * W_), lds, \
                        (hipStream_t)stream, a, (const T*)V, D, delta, part, -1, 0)
 #define CALL4(G_, NV_) CALLW(G_, NV_, 4)
 #define CALL8(G_, NV_) CALLW(G_, NV_, 8)
-    if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
+        if (waves == 8) { TMF_DISPATCH(T, geom, CALL8); } else { TMF_DISPATCH(T, geom, CALL4); }
 #undef CALL4
 #undef CALL8
 #undef CALLW
+    }
     return check_launch("tmf_wmrb_gradu3");
+}
+
+static size_t gradu4_workspace(int64_t n_users, int n_slices, int64_t users_per_launch) {
+    const int64_t launches = users_per_launch > 0 ? (n_users + users_per_launch - 1) / users_per_launch : 0;
+    return (size_t)launches * (size_t)n_slices * 8 * kSyncStride * sizeof(int);
+}
+
+extern "C" size_t tmf_wmrb_gradu4_workspace_bytes(int32_t n_users, int32_t n_slices, int32_t users_per_launch) {
+    return gradu4_workspace(n_users, n_slices, users_per_launch);
+}
+
+template <typename T>
+static int wmrb_gradu4_impl(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V, const void* U_old,
+                            void* U_out, int n_components, int epi, tmf_adam adam, int32_t users_per_launch, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    SliceLists a;
+    const RowGeom geom = row_geom_of<T>(n_components);
+    constexpr int W4 = 8;
+    if (int rc = check_lists(lists, a, "wmrb_gradu4", geom.G, W4)) return rc;
+    if (a.n_users == 0) return TMF_OK;
+    TMF_REQUIRE(D && delta && V && U_out && (epi == TMF_EPI_GRAD || U_old), "wmrb_gradu4: null pointer");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_gradu4: bad epilogue %d", epi);
+    TMF_REQUIRE(users_per_launch > 0, "wmrb_gradu4: users_per_launch=%d", users_per_launch);
+    if (geom.G < 8) {   // the offsets cache holds G slices per refill
+        set_error("wmrb_gradu4: rows of %d lanes are too narrow for the row-stationary form; use tmf_wmrb_gradu3 + tmf_wmrb_finish", geom.G);
+        return TMF_E_UNSUPPORTED;
+    }
+    constexpr int K4 = 4;
+    const int cap = geom.G < 16 ? geom.G : 16;
+    const size_t lds = (size_t)(64 / geom.G) * W4 * 2 * K4 * 2 * cap * sizeof(int);
+    const int64_t per_block = (int64_t)(64 / geom.G) * W4 * K4;
+    // per-launch rendezvous counters (optional): zeroed here, one int per (launch, slice)
+    int* sync = nullptr;
+    if (workspace != nullptr) {
+        const size_t need = gradu4_workspace(a.n_users, a.nsl, users_per_launch);
+        TMF_REQUIRE(workspace_bytes >= need, "wmrb_gradu4: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+        if (hipMemsetAsync(workspace, 0, need, (hipStream_t)stream) != hipSuccess) { set_error("wmrb_gradu4: hipMemsetAsync failed"); return TMF_E_LAUNCH; }
+        sync = static_cast<int*>(workspace);
+    }
+    int lag = 1;
+    if (const char* env = getenv("TMF_G4_LAG")) lag = atoi(env);
+    if (getenv("TMF_DEBUG")) {
+        int nb = -1, dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+#define CALL(G_, NV_) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmrb_gradu4<G_, NV_, T, K4, W4>, 64 * W4, lds)
+        TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+        fprintf(stderr, "[tmf] gradu4: %d workgroups per CU x %d CUs resident, %lld users per workgroup, lds %zu, lag %d\n", nb, cus,
+                (long long)per_block, lds, lag);
+    }
+    for (int64_t b = 0, launch = 0; b < a.n_users; b += users_per_launch, ++launch) {
+        const int64_t e = (b + users_per_launch < a.n_users) ? b + users_per_launch : a.n_users;
+        const unsigned blocks = (unsigned)((e - b + per_block - 1) / per_block);
+        int* sy = (sync && lag >= 0) ? sync + launch * a.nsl * 8 * kSyncStride : nullptr;
+#define CALL(G_, NV_)                                                                                                         \
+    hipLaunchKernelGGL((k_wmrb_gradu4<G_, NV_, T, K4, W4>), dim3(blocks), dim3(64 * W4), lds, (hipStream_t)stream, a, (const T*)V, \
+                       D, delta, (const T*)U_old, U_out, epi, adam, b, e, sy, lag)
+        TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    }
+    return check_launch("tmf_wmrb_gradu4");
 }
 
 template <typename T>
@@ -777,6 +1045,12 @@ static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users
                                          const void* V, float* part, int per_slice_launches, int n_components,            \
                                          void* stream) {                                                                  \
         return wmrb_gradu3_impl<T_>(lists, D, delta, V, part, per_slice_launches, n_components, stream);                  \
+    }                                                                                                                     \
+    extern "C" int tmf_wmrb_gradu4_##SFX(const tmf_slice_lists* lists, const float* D, const float* delta, const void* V,  \
+                                         const void* U_old, void* U_out, int n_components, int epi, tmf_adam adam,       \
+                                         int32_t users_per_launch, void* workspace, size_t workspace_bytes, void* stream) { \
+        return wmrb_gradu4_impl<T_>(lists, D, delta, V, U_old, U_out, n_components, epi, adam, users_per_launch, workspace, \
+                                    workspace_bytes, stream);                                                            \
     }                                                                                                                     \
     extern "C" int tmf_wmrb_finish_##SFX(const float* part, int32_t n_slices, int32_t n_users, const void* U_old,         \
                                          void* U_out, int n_components, int epi, tmf_adam adam, void* stream) {           \

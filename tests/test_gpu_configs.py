@@ -221,3 +221,40 @@ def test_hinge_kernel_alone(tm, case):  # noqa: F811
     assert rel_err(got[0], r_delta) < 1e-5 and rel_err(got[1], r_D) < 1e-5
     assert np.abs(got[2] - r_loss).max() <= 1e-5 * max(np.abs(r_loss).max(), 1e-30)
     assert (got[0][~(val > 0)] == 0).all()
+
+
+def test_slice_grids_beyond_one_launch(tm, monkeypatch):  # noqa: F811
+    """A HIP launch carries < 2^32 work-items.  1.1M users x 512 slices is 34375 user groups x 512 slices x 256 threads =
+    4.5e9 for the slice-major kernels: they have to go out in several launches of whole slices (found in round 3, when such a
+    grid was truncated silently and most (user, slice) ranges were skipped).  One epoch against the C oracle, in both block
+    orders, plus the row-stationary gradU."""
+    from oracle import sparse_c as C
+    rng = np.random.default_rng(11)
+    m, n, r, S_ = 1_100_000, 1024, 32, 16   # c = n / S = 64: a larger ratio amplifies the rounding of barely active hinge terms
+    u = rng.integers(0, m, 2_400_000)
+    j = rng.integers(0, n, 2_400_000)
+    key = np.unique(u.astype(np.int64) * n + j)
+    idx = np.stack([key // n, key % n], axis=1)
+    val = rng.integers(-1, 6, len(key)).astype(np.float32)
+    U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
+    V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
+    R = np.stack([rng.permutation(n)[:S_] for _ in range(4096)])
+    R = R[rng.integers(0, 4096, m)].astype(np.int32)       # distinct per row; rows drawn from 4096 patterns (a fast generator)
+    lr = 0.05
+    plan = C.Plan(idx, val, m, n, R)
+    C.set_threads(16)
+    Uc, Vc, mean, t = C.wmrb_epoch(U0, V0, plan, n, S_, lr)
+    sl = C.wmrb_boundary_slack(U0, V0, plan, n, S_)
+    monkeypatch.setenv('TMF_ITEM_SLICES', '512')
+    for xcd, rs in (('0', '0'), ('1', '0'), ('0', '1')):
+        monkeypatch.setenv('TMF_SLICE_XCD', xcd)
+        monkeypatch.setenv('TMF_ROW_STATIONARY', rs)
+        model = fit_model(tm, U0, V0, idx, val, (m, n), 1, lr, 'wmrb', R, n, S_)
+        w = model._state.wplan
+        assert w.sliced and w.n_slices == 512 and model._state.row_stationary == (rs == '1')
+        assert abs(model.loss_history_[0] - mean) <= 1e-5 * abs(mean)
+        assert_close_with_slack(w.D_in_model_order().cpu().numpy(), t['D'], sl['D'], what=f'D xcd={xcd} rs={rs}')
+        assert_step(model.user_embedding.cpu().numpy(), U0, t['gU'], lr, what=f'U xcd={xcd} rs={rs}', slack=sl['gU'])
+        assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], lr, what=f'V xcd={xcd} rs={rs}', slack=sl['gV'])
+        del model
+        torch.cuda.empty_cache()

@@ -281,6 +281,8 @@ def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, xcd):
     sliced = fit_model(tm, g['U0'], g['V0'], g['indices'], g['values'], g['A'].shape, 25, 0.1, 'wmrb', g['R'], 100, 50)
     assert rel_err(sliced.loss_history_[:3], g['loss'][:3]) < 1e-5 and rel_err(sliced.loss_history_, g['loss']) < 2e-3
     monkeypatch.setenv('TMF_USER_CHUNKS', '3')
+    # rows of 32 lanes: also through the row-stationary gradU (tmf_wmrb_gradu4: lane groups own users, walk the slices themselves)
+    monkeypatch.setenv('TMF_ROW_STATIONARY', '1' if slices in ('5', '64') else '0')
     rng = np.random.default_rng(int(slices))
     m, n, r, S_ = 41, 67, 100, 23
     A = (rng.random((m, n)) < 0.15) * rng.integers(-1, 6, (m, n))
@@ -288,7 +290,8 @@ def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, xcd):
     U0 = (rng.standard_normal((m, r)) * 0.3).astype(np.float32)
     V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
     R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
-    check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
+    model, _ = check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
+    assert model._state.row_stationary == (slices in ('5', '64'))
 
 
 @pytest.mark.parametrize('forced_slices', [None, '3'])

@@ -32,15 +32,30 @@ with open(os.path.join(dst, f'{tag}_kernel_stats.csv'), 'w') as f:
     w.writerow(cols)
     for r in rows[:25]:
         w.writerow([r[c][:160] if c == 'Name' else r[c] for c in cols])
+def kernel_key(r, seen):
+    """Kernel name without arguments; the two launches per epoch of tmf::k_mse_pass are told apart by dispatch order
+    (first = user pass, CSR; second = item pass, CSC) and keyed '... [user pass]' / '... [item pass]'."""
+    name = r['Kernel_Name']
+    if name.startswith('_ZN3tmf'):   # bf16 instantiations come out mangled (the _BFloat16 template argument)
+        name = demangle(name)
+    if 'tmf::' not in name:
+        return None
+    k = name.split('(')[0].replace('void ', '')
+    if 'k_mse_pass' in k:
+        ids = seen.setdefault(k, [])
+        if r['Dispatch_Id'] not in ids:
+            ids.append(r['Dispatch_Id'])
+        k += ' [user pass]' if ids.index(r['Dispatch_Id']) % 2 == 0 else ' [item pass]'
+    return k
+
+
 out = {}
 for kind, cn in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
-    agg, meta = collections.defaultdict(list), {}
-    for r in csv.DictReader(open(glob.glob(f'{src}/{kind}/*/*_counter_collection.csv')[0])):
-        name = r['Kernel_Name']
-        if name.startswith('_ZN3tmf'):   # bf16 instantiations come out mangled (the _BFloat16 template argument)
-            name = demangle(name)
-        if 'tmf::' in name:
-            k = name.split('(')[0].replace('void ', '')
+    agg, meta, seen = collections.defaultdict(list), {}, {}
+    rows_ = sorted(csv.DictReader(open(glob.glob(f'{src}/{kind}/*/*_counter_collection.csv')[0])), key=lambda r: int(r['Dispatch_Id']))
+    for r in rows_:
+        k = kernel_key(r, seen)
+        if k is not None:
             agg[k].append(float(r['Counter_Value']))
             meta[k] = dict(vgpr=r['VGPR_Count'], agpr=r['Accum_VGPR_Count'], sgpr=r['SGPR_Count'], lds=r['LDS_Block_Size'],
                            workgroup=r['Workgroup_Size'], grid=r['Grid_Size'])
@@ -51,13 +66,11 @@ for kind, cn in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         d.update(meta[k])
 tcc = glob.glob(f'{src}/pmc_tcc/*/*_counter_collection.csv')
 if tcc:   # L2 hit rate per kernel: TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), summed over the launches
-    hm = collections.defaultdict(lambda: [0.0, 0.0])
-    for r in csv.DictReader(open(tcc[0])):
-        name = r['Kernel_Name']
-        if name.startswith('_ZN3tmf'):
-            name = demangle(name)
-        if 'tmf::' in name and r['Counter_Name'] in ('TCC_HIT_sum', 'TCC_MISS_sum'):
-            hm[name.split('(')[0].replace('void ', '')][r['Counter_Name'] == 'TCC_MISS_sum'] += float(r['Counter_Value'])
+    hm, seen = collections.defaultdict(lambda: [0.0, 0.0]), {}
+    for r in sorted(csv.DictReader(open(tcc[0])), key=lambda r: int(r['Dispatch_Id'])):
+        k = kernel_key(r, seen)
+        if k is not None and r['Counter_Name'] in ('TCC_HIT_sum', 'TCC_MISS_sum'):
+            hm[k][r['Counter_Name'] == 'TCC_MISS_sum'] += float(r['Counter_Value'])
     for k, (h, mi) in hm.items():
         if h + mi > 0:
             out.setdefault(k, {}).update(TCC_HIT_sum=h, TCC_MISS_sum=mi, l2_hit_rate=h / (h + mi))

@@ -14,7 +14,8 @@ g = torch.Generator(device=dev).manual_seed(1)
 U = torch.randn(m, r, device=dev, generator=g) * 0.1
 V = torch.randn(n, r, device=dev, generator=g) * 0.1
 R = random_sampler_device(n, m, S, seed=5, device=dev)
-Rs = torch.sort(R, dim=1)[0].contiguous()
+Rs_flat = torch.cat([torch.sort(R, dim=1)[0].flatten(), torch.zeros(64, dtype=torch.int32, device=dev)])   # padded: the kernels read a few ids ahead
+Rs = Rs_flat[:m * S].view(m, S)
 sp = torch.zeros(m, S, device=dev)
 ptr = lambda t: ctypes.c_void_p(t.data_ptr())
 
@@ -52,5 +53,15 @@ for threads, T, blocks in [(512, 296, 256)]:
     err = float((sp - sp_ref).abs().max()); ref = float(sp_ref.abs().max())
     print('proto threads=%d T=%d blocks=%d: %.2f ms   max|diff| %.3g (max|ref| %.3g)' % (threads, T, blocks, t, err, ref), flush=True)
 
+def run_proto2(T, threads, blocks, mode=0):
+    rc = P.proto_scores_lds2(ptr(U), ptr(V), ptr(Rs), ptr(sp), m, n, S, T, threads, blocks, mode, None)
+    assert rc == 0, rc
+for threads, T, blocks in [(512, 296, 256)]:
+    sp.zero_()
+    t = timeit(lambda: run_proto2(T, threads, blocks))
+    err = float((sp - sp_ref).abs().max())
+    print('proto2 threads=%d T=%d blocks=%d: %.2f ms   max|diff| %.3g' % (threads, T, blocks, t, err), flush=True)
+for mode in (1, 2, 3):
+    print('proto2 mode', mode, '(1 = no stores, 2 = synthetic ids) %.2f ms' % timeit(lambda: run_proto2(296, 512, 256, mode)), flush=True)
 for mode, name in ((1, 'no tile loads'), (2, 'no compute'), (3, 'no per-entry store'), (4, 'no store, synthetic ids (no id loads)')):
     print(name, '%.2f ms' % timeit(lambda: run_proto(296, 512, 256, mode)), flush=True)
