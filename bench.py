@@ -403,8 +403,9 @@ class Workload:
             self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
             ns, sliced = _engine.choose_wmrb_user_pass(m, n, _lib.padded_ld(r, torch.bfloat16) if dtype == 'bf16' else ld, S, self.plan.n_pos, r,
                                                        elem_size=2 if dtype == 'bf16' else 4)
-            self.wplan = _engine.WmrbPlan(self.plan, self.R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n),
-                                          item_slices=ns, n_components=r, sliced=sliced)
+            rows4 = _engine.rows4_wanted(r, torch.bfloat16 if dtype == 'bf16' else torch.float32, self.plan, self.R)
+            self.wplan = _engine.WmrbPlan(self.plan, self.R, user_chunks=_engine.default_user_chunks(m, ld, n_items=None if rows4 else n),
+                                          item_slices=ns, n_components=r, sliced=sliced, rows4=rows4)
         self.st = _engine.TrainState(U0, V0, self.plan, r, self.wplan, dtype=torch.bfloat16 if dtype == 'bf16' else torch.float32)
         self.adam = _engine.adam_constants(args.lr)
         self.c = n / S
@@ -416,7 +417,7 @@ class Workload:
         s = 2 if self.dtype == 'bf16' else 4
         if self.loss == 'wmrb':
             return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced,
-                                      int(w.rowptr_e[-1]), w.seg_e.n_slab, w.user_chunks,
+                                      int(w.rowptr_e[-1]), w.seg_e.n_slab if w.seg_e is not None else 0, w.user_chunks,
                                       getattr(st, 'part_layers', None))
         return mse_kernel_models(self.m, self.n, self.nnz, st.ld, s)
 

@@ -136,6 +136,19 @@ int tmf_wsum_pass_f32(const tmf_segments* seg, const int32_t* ent_row, const int
                       const float* wbuf, const float* T, const float* X_old, float* X_out,
                       float* slab, int n_components, int epi, tmf_adam adam, void* stream);
 
+/* Row-stationary form of tmf_wsum_pass + tmf_combine_rows over user-blocked lists (speed only): the lists are those of
+ * tmf_wmrb_entry_lists with `n_blocks` user blocks - list row = block * n_rows + i, rowptr [n_blocks * n_rows + 1] - but a
+ * lane group owns a few consecutive output rows i, keeps their sums in registers and walks the blocks itself: no slab, no
+ * combine.  g[i] = sum over blocks (ascending) and list entries e of wbuf[ent_w[e]] * T[ent_row[e]], then the epilogue.
+ * The rows are launched `rows_per_launch` at a time (a multiple of tmf_wsum_rows4_rows_per_group(); all workgroups of a
+ * launch resident together); workspace (optional): tmf_wsum_rows4_workspace_bytes() of device memory for the per-block
+ * rendezvous counters, zeroed by the call.  Rows of at least 16 lanes. */
+int tmf_wsum_rows4_rows_per_group(int n_components, int bf16);
+size_t tmf_wsum_rows4_workspace_bytes(int32_t n_rows, int32_t n_blocks, int32_t rows_per_launch);
+int tmf_wsum_rows4_f32(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row, const int32_t* ent_w,
+                       const float* wbuf, const float* T, const float* X_old, float* X_out, int n_components, int epi,
+                       tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Finishes the rows that tmf_*_pass cut into several segments: g[row] = sum of its slab slots
  * [slab_beg[i], slab_beg[i+1]) in order, then the epilogue. */
 int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
@@ -268,6 +281,9 @@ int tmf_mse_pass_bf16(const tmf_segments* seg, const int32_t* other, const float
 int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_row, const int32_t* ent_w,
                        const float* wbuf, const void* T, const void* X_old, void* X_out,
                        float* slab, int n_components, int epi, tmf_adam adam, void* stream);
+int tmf_wsum_rows4_bf16(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row, const int32_t* ent_w,
+                        const float* wbuf, const void* T, const void* X_old, void* X_out, int n_components, int epi,
+                        tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream);
 int tmf_combine_rows_bf16(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
                           const float* slab, const void* X_old, void* X_out, int n_components,
                           int epi, tmf_adam adam, void* stream);

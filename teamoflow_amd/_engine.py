@@ -282,6 +282,28 @@ def choose_wmrb_user_pass(n_users, n_items, ld, n_samples, n_positives, n_compon
     return 1, False
 
 
+def rows4_wanted(n_components, dtype=torch.float32, plan=None, R=None):
+    """The row-stationary item pass (tmf_wsum_rows4: lane groups own items and walk the user blocks, no slab, no combine) is
+    opt-in (TMF_ROWS4=1) and needs rows of at least 16 lanes; everything else takes tmf_wsum_pass + tmf_combine_rows.
+    It gives every lane group the same NUMBER of items, so a catalog with a few very popular items (power-law positives: the
+    top item of C4 has ~1M list entries against 11K on average) would leave a launch waiting for the lane groups that own
+    them - measured 1725 ms against 83 ms at the config-5 shard: with `plan` / `R` given, such catalogs are refused here."""
+    if os.environ.get('TMF_ROWS4') != '1':
+        return False
+    if not _lib.load_library().tmf_wsum_rows4_rows_per_group(int(n_components), int(dtype is torch.bfloat16)):
+        return False
+    if plan is not None and R is not None and plan.n_items:
+        per_item = torch.bincount(plan.col_u[plan.val_u > 0].to(torch.int64), minlength=plan.n_items)
+        per_item += torch.bincount(R.reshape(-1).to(torch.int64), minlength=plan.n_items)[:plan.n_items]
+        mean = float(per_item.to(torch.float64).mean())
+        if float(per_item.max()) > 4.0 * max(mean, 1.0):
+            import warnings
+            warnings.warn(f'row-stationary item pass (TMF_ROWS4) not used: the most popular item has {int(per_item.max())} list '
+                          f'entries against {mean:.0f} on average')
+            return False
+    return True
+
+
 def fused_user_pass_fits(n_samples, n_components):
     """The one-kernel user pass keeps a user's scores and D in LDS; above ~13K negatives they do not fit and the sliced
     pass (no such limit) takes over whatever the catalog size."""
@@ -301,7 +323,7 @@ class WmrbPlan:
     negative / interaction of every item slice."""
 
     def __init__(self, plan, R, chunk=DEFAULT_CHUNK, user_chunks=1, item_slices=1, n_components=128, sliced=None, item_lists=True,
-                 xcd_major=None):
+                 xcd_major=None, rows4=False):
         dev = R.device
         m, S = R.shape
         nnz, n = plan.nnz, plan.n_items
@@ -369,8 +391,9 @@ class WmrbPlan:
             ent_id = ent_id.to(torch.int32)
         self.rowptr_e = rowptr[:C * n + 1].contiguous()  # the row behind them holds the stored values <= 0: never read
         self.ent_w = ent_id
-        if not item_lists:
-            self.seg_e = None   # the caller cuts the lists into windows itself (SegmentTable.of_rows)
+        self.rows4 = bool(rows4)
+        if not item_lists or self.rows4:
+            self.seg_e = None   # the caller cuts the lists into windows itself (SegmentTable.of_rows) / row-stationary item pass
         elif C > 1:
             out_row = torch.arange(C * n, device=dev) % n
             self.seg_e = SegmentTable(self.rowptr_e, chunk, out_row=out_row, n_out=n)
@@ -429,7 +452,8 @@ class TrainState:
         else:
             self.V, self.V_nxt = V_tables
         self.plan, self.wplan = plan, wplan
-        need = dict(slab=max(plan.seg_u.n_slab, plan.seg_i.n_slab if plan.seg_i else 0, wplan.seg_e.n_slab if wplan else 0, 1) * self.ld,
+        need = dict(slab=max(plan.seg_u.n_slab, plan.seg_i.n_slab if plan.seg_i else 0,
+                             wplan.seg_e.n_slab if wplan is not None and wplan.seg_e is not None else 0, 1) * self.ld,
                     loss_part=max(plan.seg_u.nseg, plan.n_users, 1))
         self.row_stationary = False
         if wplan is not None and wplan.sliced:
@@ -450,6 +474,15 @@ class TrainState:
             else:
                 self.part_layers, self.gradu_launches = 1, 1           # a launch per slice
             need.update(sp=m * S, pk=max(plan.nnz, 1), part=self.part_layers * max(m, 1) * self.ld)
+        if wplan is not None and wplan.rows4:
+            L = _lib.load_library()
+            per_group = L.tmf_wsum_rows4_rows_per_group(self.r, int(dtype is torch.bfloat16))
+            if not per_group:
+                raise ValueError('the row-stationary item pass needs rows of at least 16 lanes')
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count if torch.cuda.is_available() else 256
+            self.rows4_per_launch = int(os.environ.get('TMF_ROWS4_PER_LAUNCH', 2 * cus * per_group))   # two workgroups per CU resident
+            nb = L.tmf_wsum_rows4_workspace_bytes(plan.n_items, wplan.user_chunks, self.rows4_per_launch)
+            self.rows4_sync = torch.zeros(max(nb // 4, 1), dtype=torch.int32, device=dev)
         self._need = need
         if scratch is None:
             self._bind({k: torch.zeros(v, dtype=torch.float32, device=dev) if k == 'loss_part'
@@ -598,6 +631,19 @@ def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, pro
         prof.stop('wmrb_user_pass')
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)
     V_out = st.V_nxt if item_out is None else item_out
+    if w.rows4:
+        # row-stationary item pass: lane groups own items and walk the user blocks; no slab, no combine
+        if prof:
+            prof.start('wmrb_item_pass')
+        n_rows = st.V.shape[0]
+        _lib.check(getattr(lib, 'tmf_wsum_rows4' + st.sfx)(_lib.ptr(w.rowptr_e), ctypes.c_int32(p.n_items), ctypes.c_int32(w.user_chunks),
+                                                           _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf), _lib.ptr(st.U),
+                                                           _lib.ptr(st.V), _lib.ptr(V_out), r, item_epi, adam,
+                                                           ctypes.c_int32(st.rows4_per_launch), _lib.ptr(st.rows4_sync),
+                                                           st.rows4_sync.numel() * 4, s), lib)
+        if prof:
+            prof.stop('wmrb_item_pass')
+        return
     if prof:
         prof.start('wmrb_item_pass')
     _lib.check(getattr(lib, 'tmf_wsum_pass' + st.sfx)(w.seg_e.cstruct(), _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf),

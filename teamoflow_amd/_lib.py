@@ -67,6 +67,9 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_entry_lists': (_I, [_P, _P, _P, _L, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
     'tmf_mse_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_pass_f32': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_wsum_rows4_rows_per_group': (_I, [_I, _I]),
+    'tmf_wsum_rows4_workspace_bytes': (_SZ, [_I32, _I32, _I32]),
+    'tmf_wsum_rows4_f32': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _I32, _P, _SZ, _P]),
     'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_fits': (_I, [_I32, _I]),
@@ -81,6 +84,7 @@ _BASE_SIGNATURES = {
     'tmf_adam_step': (Adam, [_F, _I]),
     'tmf_adam_state_rows_f32': (_I, [_P, _P, _P, _P, _L, _I, Adam, _P]),
     'tmf_mse_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
+    'tmf_wsum_rows4_bf16': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _I32, _P, _SZ, _P]),
     'tmf_wsum_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_bf16': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_bf16': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),

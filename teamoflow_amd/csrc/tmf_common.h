@@ -329,6 +329,34 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// v of lane `idx` of this lane group (ds_bpermute: every lane of the wave has to execute it)
+template <int G>
+__device__ __forceinline__ int group_read(int v, int idx) {
+    return __shfl(v, (threadIdx.x & 63 & ~(G - 1)) + idx, 64);
+}
+
+// Soft rendezvous of the workgroups of a launch, once per step i (speed only - no data is handed over, so no fences):
+// "I have finished step i" is one relaxed agent-scope add; before going on, wait until every workgroup of this block's XCD
+// lane (blocks b and b + 8 share an XCD under the observed round-robin placement, and a window has to stay resident per XCD
+// L2 only) has finished step i - lag, so those workgroups are spread over at most lag + 1 windows.  One counter per
+// (step, lane), each on a 64-byte line of its own.  The wait is BOUNDED: if a workgroup of the launch is not resident (or
+// the counters are stale) the others give up after ~50 us and run on, unsynchronised but correct - a launch never hangs.
+constexpr int kSyncStride = 16;   // ints between counters
+__device__ __forceinline__ void step_rendezvous(int* sync, int i, int lag, int n_groups) {
+    const int x = blockIdx.x & 7;
+    const int mine = (n_groups - x + 7) / 8;   // workgroups of this lane
+    __hip_atomic_fetch_add(sync + (i * 8 + x) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int need = i - lag;
+    if (need < 0) return;
+    for (int spin = 0; spin < 256; ++spin) {
+        if (__hip_atomic_load(sync + (need * 8 + x) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+inline size_t rendezvous_bytes(int64_t launches, int64_t steps) {
+    return (size_t)launches * (size_t)steps * 8 * kSyncStride * sizeof(int);
+}
+
 // Sum over the G lanes of a group (lanes [G*k, G*k+G)); every lane of the group ends with the same bits
 // (x+y == y+x at every level), so the value can be used as a per-entry weight by all of them.
 // Pure VALU: DPP quad permutes (lane^1, lane^2), row_half_mirror / row_mirror (the other quad / the other

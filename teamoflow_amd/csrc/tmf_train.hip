@@ -228,6 +228,82 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-stationary weighted gather-sum ("rows4"): a lane group OWNS up to K consecutive output rows (items), keeps their
+// sums in registers and walks the user blocks itself: the entry lists are the same per-(user block, item) lists the pass
+// above consumes (list row = block * n_rows + item), but no list produces a partial row - no slab, no combine.  In block t
+// the lists of the lane group's items are ONE contiguous range of entries, staged flat (row id + gathered weight) in tiles of
+// kRows4Tile; item k takes its part of every tile.  A launch covers as many rows as are resident together, so the
+// workgroups walk the blocks in loose lockstep (one workgroup barrier + one bounded rendezvous per block) and the block of U
+// rows being gathered from stays in the L2s.
+// Sum order of a row: blocks ascending, list order inside a block - ONE running fp32 sum (the slab form adds per-block
+// partial sums), so the two forms agree to rounding, not to the bit.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRows4Tile = 64;
+
+template <int G, int NV, typename T, int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wsum_rows4(
+    const int64_t* __restrict__ rowptr, int64_t n_rows, int n_blocks, const int32_t* __restrict__ ent_row,
+    const int32_t* __restrict__ ent_w, const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
+    void* __restrict__ X_out, int epi, tmf_adam adam, int64_t row_begin, int64_t row_end, int* __restrict__ sync, int lag) {
+    static_assert(K + 1 <= G, "the list boundaries of a block live in one register of the lane group");
+    constexpr int NG = 64 / G, NGB = NG * WAVES;
+    __shared__ int s_ids[NGB][kRows4Tile];
+    __shared__ float s_w[NGB][kRows4Tile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane & (G - 1), gid = wave * NG + lane / G;
+    int* ids = s_ids[gid];
+    float* ws = s_w[gid];
+    const int64_t j0 = row_begin + ((int64_t)blockIdx.x * NGB + gid) * K;
+    const int kv = (int)((row_end - j0 < K) ? (row_end > j0 ? row_end - j0 : 0) : K);   // rows this lane group really owns
+    Frag<NV> acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) zero<NV>(acc[k]);
+    for (int t = 0; t < n_blocks; ++t) {
+        // lane l <= kv: first entry of the list (block t, row j0 + l); entries fit 31 bits (include/tmf.h)
+        const int bnd = (kv > 0) ? (int)rowptr[(int64_t)t * n_rows + j0 + (g < kv ? g : kv)] : 0;
+        const int r_beg = group_read<G>(bnd, 0), r_end = group_read<G>(bnd, kv);
+        int b[K + 1];
+#pragma unroll
+        for (int k = 0; k <= K; ++k) b[k] = group_read<G>(bnd, k < kv ? k : kv);
+        for (int c0 = r_beg; c0 < r_end; c0 += kRows4Tile) {
+            const int cnt = (r_end - c0 < kRows4Tile) ? r_end - c0 : kRows4Tile;
+            for (int e = g; e < cnt; e += G) {
+                ids[e] = ent_row[c0 + e];
+                ws[e] = wbuf[ent_w[c0 + e]];
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int lo = (b[k] > c0 ? b[k] : c0) - c0;
+                const int hi = ((b[k + 1] < c0 + cnt) ? b[k + 1] : c0 + cnt) - c0;
+                for (int e0 = lo; e0 < hi; e0 += kUnroll) {
+                    Raw<NV, T> raw[kUnroll];
+                    float wc[kUnroll];
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        const int e = e0 + u;
+                        wc[u] = (e < hi) ? ws[e] : 0.f;
+                        load_raw<G, NV>(raw[u], Tab, ids[(wc[u] != 0.f) ? e : lo], g);   // weight 0: an L1-hot row times 0
+                    }
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        Frag<NV> y;
+                        to_frag<NV>(y, raw[u]);
+                        axpy<NV>(acc[k], wc[u], y);
+                    }
+                }
+            }
+            wave_lds_sync();   // the next tile rewrites the stage
+        }
+        if (sync != nullptr && tid == 0) step_rendezvous(sync, t, lag, (int)gridDim.x);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (k < kv) row_epilogue<G, NV, T>(acc[k], X_old, X_out, j0 + k, g, epi, adam);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Rows cut into several segments: sum the slab slots in slot order (group t takes slots t, t+NG..
 // then the fixed butterfly over groups), then the epilogue.
 // ---------------------------------------------------------------------------------------------
@@ -454,6 +530,81 @@ extern "C" int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_ro
                                   const float* wbuf, const void* T, const void* X_old, void* X_out,
                                   float* slab, int n_components, int epi, tmf_adam adam, void* stream) {
     return wsum_pass_impl<__bf16>(seg, ent_row, ent_w, wbuf, T, X_old, X_out, slab, n_components, epi, adam, stream);
+}
+
+template <typename T>
+static int wsum_rows4_impl(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row, const int32_t* ent_w,
+                           const float* wbuf, const void* Tab, const void* X_old, void* X_out, int n_components, int epi,
+                           tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_rows == 0) return TMF_OK;
+    TMF_REQUIRE(n_rows > 0 && n_blocks > 0 && rows_per_launch > 0, "wsum_rows4: n_rows=%d n_blocks=%d rows_per_launch=%d", n_rows,
+                n_blocks, rows_per_launch);
+    TMF_REQUIRE(rowptr && ent_row && ent_w && wbuf && Tab && X_out && (epi == TMF_EPI_GRAD || X_old), "wsum_rows4: null pointer");
+    TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wsum_rows4: bad epilogue %d", epi);
+    const RowGeom geom = row_geom_of<T>(n_components);
+    if (geom.G < 16) {
+        set_error("wsum_rows4: rows of %d lanes are too narrow for the row-stationary form; use tmf_wsum_pass + tmf_combine_rows", geom.G);
+        return TMF_E_UNSUPPORTED;
+    }
+    constexpr int W4 = 8;
+    const int K4 = geom.NV >= 2 ? 8 : 15;   // rows per lane group: 8 x 8 or 15 x 4 accumulator registers
+    const int64_t per_block = (int64_t)(64 / geom.G) * W4 * K4;
+    const int64_t launches = ((int64_t)n_rows + rows_per_launch - 1) / rows_per_launch;
+    int* sync = nullptr;
+    int lag = 1;
+    if (const char* env = getenv("TMF_G4_LAG")) lag = atoi(env);
+    if (workspace != nullptr && lag >= 0) {
+        const size_t need = rendezvous_bytes(launches, n_blocks);
+        TMF_REQUIRE(workspace_bytes >= need, "wsum_rows4: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+        if (hipMemsetAsync(workspace, 0, need, (hipStream_t)stream) != hipSuccess) { set_error("wsum_rows4: hipMemsetAsync failed"); return TMF_E_LAUNCH; }
+        sync = static_cast<int*>(workspace);
+    }
+    for (int64_t b = 0, launch = 0; b < n_rows; b += rows_per_launch, ++launch) {
+        const int64_t e = (b + rows_per_launch < n_rows) ? b + rows_per_launch : n_rows;
+        const unsigned blocks = (unsigned)((e - b + per_block - 1) / per_block);
+        int* sy = sync ? sync + launch * n_blocks * 8 * kSyncStride : nullptr;
+#define CALLK(G_, NV_, K_)                                                                                                     \
+    hipLaunchKernelGGL((k_wsum_rows4<G_, NV_, T, K_, W4>), dim3(blocks), dim3(64 * W4), 0, (hipStream_t)stream, rowptr,          \
+                       (int64_t)n_rows, (int)n_blocks, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, epi, adam, b, \
+                       e, sy, lag)
+        if constexpr (std::is_same<T, float>::value) {
+            if (geom.NV == 1 && geom.G == 16) { CALLK(16, 1, 15); }
+            else if (geom.NV == 1 && geom.G == 32) { CALLK(32, 1, 15); }
+            else if (geom.NV == 1 && geom.G == 64) { CALLK(64, 1, 15); }
+            else if (geom.NV == 2 && geom.G == 64) { CALLK(64, 2, 8); }
+            else { set_error("wsum_rows4: unsupported n_components"); return TMF_E_UNSUPPORTED; }
+        } else {
+            if (geom.NV == 2 && geom.G == 16) { CALLK(16, 2, 8); }
+            else if (geom.NV == 2 && geom.G == 32) { CALLK(32, 2, 8); }
+            else if (geom.NV == 2 && geom.G == 64) { CALLK(64, 2, 8); }
+            else { set_error("wsum_rows4: unsupported n_components"); return TMF_E_UNSUPPORTED; }
+        }
+#undef CALLK
+    }
+    return check_launch("tmf_wsum_rows4");
+}
+
+extern "C" int tmf_wsum_rows4_rows_per_group(int n_components, int bf16) {
+    const RowGeom geom = bf16 ? row_geom_bf16(n_components) : row_geom(n_components);
+    if (geom.ld == 0 || geom.G < 16 || (geom.NV != 1 && geom.NV != 2)) return 0;
+    return (64 / geom.G) * 8 * (geom.NV >= 2 ? 8 : 15);   // rows one 512-thread workgroup owns
+}
+extern "C" size_t tmf_wsum_rows4_workspace_bytes(int32_t n_rows, int32_t n_blocks, int32_t rows_per_launch) {
+    return rows_per_launch > 0 ? rendezvous_bytes(((int64_t)n_rows + rows_per_launch - 1) / rows_per_launch, n_blocks) : 0;
+}
+extern "C" int tmf_wsum_rows4_f32(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row,
+                                  const int32_t* ent_w, const float* wbuf, const float* T, const float* X_old, float* X_out,
+                                  int n_components, int epi, tmf_adam adam, int32_t rows_per_launch, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    return wsum_rows4_impl<float>(rowptr, n_rows, n_blocks, ent_row, ent_w, wbuf, T, X_old, X_out, n_components, epi, adam,
+                                  rows_per_launch, workspace, workspace_bytes, stream);
+}
+extern "C" int tmf_wsum_rows4_bf16(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row,
+                                   const int32_t* ent_w, const float* wbuf, const void* T, const void* X_old, void* X_out,
+                                   int n_components, int epi, tmf_adam adam, int32_t rows_per_launch, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    return wsum_rows4_impl<__bf16>(rowptr, n_rows, n_blocks, ent_row, ent_w, wbuf, T, X_old, X_out, n_components, epi, adam,
+                                   rows_per_launch, workspace, workspace_bytes, stream);
 }
 
 extern "C" int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,

@@ -577,36 +577,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_gradu3(SliceLists a, const 
 // Sum order of a user's row: slices ascending, negatives then interactions inside a slice, entries ascending - ONE running
 // fp32 sum (gradu3 + finish add per-slice partial sums), so the two forms agree to rounding, not to the bit.
 // ---------------------------------------------------------------------------------------------
-// Soft rendezvous of the workgroups of a launch, once per slice (speed only - no data is handed over, so no fences):
-// "I have finished slice i" is one relaxed agent-scope add; before going on, wait until EVERY workgroup has finished slice
-// i - lag, so the workgroups of a launch are spread over at most lag + 1 slices and those stay in the L2s.  The wait is
-// BOUNDED: if a workgroup of the launch is not resident (or the counters are stale) the others give up after ~50 us and run
-// on, unsynchronised but correct - a launch can never hang on it.
-// One counter per (slice, XCD lane): blocks b and b + 8 share an XCD under the observed round-robin placement, and a slice has
-// to stay resident per XCD L2 only - so a workgroup meets just the workgroups of its own lane (an eighth of the arrivals per
-// counter, each on a 64-byte line of its own).
-constexpr int kSyncStride = 16;   // ints between counters
-__device__ __forceinline__ void slice_rendezvous(int* sync, int i, int lag, int n_groups) {
-    const int x = blockIdx.x & 7;
-    const int mine = (n_groups - x + 7) / 8;   // workgroups of this lane
-    __hip_atomic_fetch_add(sync + (i * 8 + x) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int need = i - lag;
-    if (need < 0) return;
-    for (int spin = 0; spin < 256; ++spin) {
-        if (__hip_atomic_load(sync + (need * 8 + x) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine) return;
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-
 template <int G>
 struct Stage4 {
     static constexpr int cap = G < 16 ? G : 16;   // entries of one (user, slice) visit staged per step; longer visits finish inline
 };
-
-template <int G>
-__device__ __forceinline__ int group_read(int v, int idx) {   // v of lane `idx` of this lane group
-    return __shfl(v, (threadIdx.x & 63 & ~(G - 1)) + idx, 64);
-}
 
 template <int G, int NV, typename T, int K, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wmrb_gradu4(   // two workgroups per CU: 4 waves per SIMD, <= 128 VGPRs
@@ -736,7 +710,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wmrb_gradu4(   // two
             }
         }
         if (more) commit(buf ^ 1);
-        if (sync != nullptr && tid == 0) slice_rendezvous(sync, sl - a.sl0, lag, (int)gridDim.x);
+        if (sync != nullptr && tid == 0) step_rendezvous(sync, sl - a.sl0, lag, (int)gridDim.x);
         __syncthreads();   // lockstep of the workgroup's lane groups (the other buffer is private to this wave: no hazard)
     }
 #pragma unroll
@@ -957,7 +931,7 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
 
 static size_t gradu4_workspace(int64_t n_users, int n_slices, int64_t users_per_launch) {
     const int64_t launches = users_per_launch > 0 ? (n_users + users_per_launch - 1) / users_per_launch : 0;
-    return (size_t)launches * (size_t)n_slices * 8 * kSyncStride * sizeof(int);
+    return rendezvous_bytes(launches, n_slices);
 }
 
 extern "C" size_t tmf_wmrb_gradu4_workspace_bytes(int32_t n_users, int32_t n_slices, int32_t users_per_launch) {

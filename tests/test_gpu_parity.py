@@ -283,6 +283,7 @@ def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, xcd):
     monkeypatch.setenv('TMF_USER_CHUNKS', '3')
     # rows of 32 lanes: also through the row-stationary gradU (tmf_wmrb_gradu4: lane groups own users, walk the slices themselves)
     monkeypatch.setenv('TMF_ROW_STATIONARY', '1' if slices in ('5', '64') else '0')
+    monkeypatch.setenv('TMF_ROWS4', '1' if slices in ('2', '64') else '0')   # and the row-stationary item pass (tmf_wsum_rows4)
     rng = np.random.default_rng(int(slices))
     m, n, r, S_ = 41, 67, 100, 23
     A = (rng.random((m, n)) < 0.15) * rng.integers(-1, 6, (m, n))
@@ -291,7 +292,7 @@ def test_wmrb_sliced_user_pass(tm, golden, monkeypatch, slices, xcd):
     V0 = (rng.standard_normal((n, r)) * 0.3).astype(np.float32)
     R = np.stack([rng.choice(n, S_, replace=False) for _ in range(m)])
     model, _ = check_one_step(tm, U0, V0, idx, val, (m, n), 0.01, 'wmrb', R, n, S_)
-    assert model._state.row_stationary == (slices in ('5', '64'))
+    assert model._state.row_stationary == (slices in ('5', '64')) and model._state.wplan.rows4 == (slices in ('2', '64'))
 
 
 @pytest.mark.parametrize('forced_slices', [None, '3'])
