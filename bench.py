@@ -231,9 +231,12 @@ def pmc_traffic(path=None):
         prefix, suffix = pat if isinstance(pat, tuple) else (pat, '')
         for k, v in d.items():
             if k.startswith(prefix) and k.endswith(suffix) and 'FETCH_SIZE_KB_mean_per_launch' in v:
-                f, w = v['FETCH_SIZE_KB_mean_per_launch'] * 1024, v.get('WRITE_SIZE_KB_mean_per_launch', 0) * 1024
+                # per EPOCH (the timers bracket all launches of a kernel in an epoch: the config-5 gradU goes out once per slice)
+                per_epoch = max(1.0, v.get('launches_FETCH_SIZE', 1) / float(d.get('_epochs_in_pmc_runs', v.get('launches_FETCH_SIZE', 1))))
+                f, w = v['FETCH_SIZE_KB_mean_per_launch'] * 1024 * per_epoch, v.get('WRITE_SIZE_KB_mean_per_launch', 0) * 1024 * per_epoch
                 wide = name != 'wmrb_hinge'   # the hinge kernel reads 4 bytes per lane: correction not calibrated, left out
-                out[name] = dict(bytes=(2 * f if wide else f) + w, bytes_uncorrected=f + w, l2_hit_rate=v.get('l2_hit_rate'))
+                out[name] = dict(bytes=(2 * f if wide else f) + w, bytes_uncorrected=f + w, l2_hit_rate=v.get('l2_hit_rate'),
+                                 launches_per_epoch=per_epoch)
     return out, os.path.relpath(path, ROOT)
 
 
