@@ -159,7 +159,15 @@ def roofline_report(models, prof, pmc=None):
             e.update(rows_gathered=k['rows'], gather_bytes=k['gather'], gather_rate_GBps=k['gather'] / t / 1e9,
                      l2_frac=k['gather'] / t / L2_PEAK)
         meas = pmc.get(name) if pmc else None
-        if k['roof'] == 'l2':
+        if k['roof'] == 'l2' and meas is not None and meas['bytes'] / t / HBM_PEAK > e['l2_frac']:
+            # blocked for the L2s, but the counters say the memory-side fabric is the tighter roof (config-5 shard: L2 hit rate
+            # 0.41, 7 - 9 TB/s of fabric traffic): price the kernel where it is bound
+            rate = meas['bytes'] / t
+            e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=min(rate / HBM_PEAK, 1.0), frac_source='pmc',
+                     note=f"blocked for the L2s (gather rate {e['gather_rate_GBps'] / 1e3:.1f} TB/s = {e['l2_frac']:.2f} of the L2 roof) but bound by the "
+                          f"memory-side fabric: measured {rate / 1e12:.2f} TB/s of L2-miss + write traffic, L2 hit rate {meas.get('l2_hit_rate')}; "
+                          "FETCH_SIZE counts Infinity-Cache hits too, so this is fabric traffic, of which HBM is an unknown share")
+        elif k['roof'] == 'l2':
             e.update(bound='l2', achieved=e['gather_rate_GBps'], peak=L2_PEAK / 1e9, frac=e['l2_frac'])
         elif k['roof'] == 'hbm' and meas is not None:
             # HBM-bound kernel with counters of this code version: the fraction is MEASURED fabric bytes (L2 misses + writes,
