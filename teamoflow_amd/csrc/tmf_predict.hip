@@ -361,34 +361,60 @@ extern "C" int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, floa
 // for the whole kernel (K/2 floats per lane); item tiles of 128 stream through a 3-slot LDS ring in
 // k-chunks of 32 (global loads for chunk g+2 are issued before the MFMAs of chunk g and written to
 // LDS after them, one barrier per chunk).  After each 128x128 tile every lane tests its 64
-// accumulator values against the per-row threshold (the row's current k-th best, in LDS) and pushes
-// the few that pass into a per-row pending buffer; one thread per row then merges them into the
-// row's sorted list under the total order (value desc, index asc).  Items arrive in ascending index
-// order, so "strictly greater than the k-th value" is exactly tf.math.top_k's tie rule.  If a row
-// gets more candidates than the pending buffer holds (always on the first tile, when the threshold
-// is -inf), the tile is re-offered in 8 column groups of 16 - same result, no extra memory.
+// accumulator values against the per-row threshold (the row's current k-th best, in registers); the few that pass reach
+// the row's sorted list under the total order (value desc, index asc) in one of two ways (template CAND):
+//   FCAND_PEND (k <= 12)  append to a per-row pending buffer (one returning LDS atomic per candidate), one lane per row merges
+//                         the buffer into the sorted list when some row of the wave has filled half of it - the serial,
+//                         LDS-latency-bound insertion then runs ~20 times per row block instead of on most tiles;
+//   FCAND_INS  (k <= 64)  insert at once with all 64 lanes: lane j holds list entry j, the candidate's position is a ballot +
+//                         popcount, everything behind it moves down one lane (DPP wave_shr:1) - no atomics, no pending
+//                         buffer, no overflow path, and k = 64 costs per insertion what k = 13 costs; thresholds are refreshed
+//                         in registers after every insertion.  One copy of the code walks the rows by a wave-uniform
+//                         register index (sixteen unrolled copies overflowed the instruction cache).
+// Items arrive in ascending index order, so "strictly greater than the k-th value" at the start of a tile is exactly
+// tf.math.top_k's tie rule; inside a tile the full comparator decides.  Measured (r = 128, 262144 x 100000, same box,
+// TF pending / insertion): k = 10: 118.5 / 115.3, 16: 89.9 / 110.0, 24: 77.1 / 103.6, 32: 65.9 / 75.7, 64: 36.4 / 61.1.
+// An insertion costs ~1000 cycles of wave time whatever holds the list (LDS or registers - both were built): it is ~160
+// dependent instructions of one wave, not memory; the pending path wins at small k because it batches them.
 // =============================================================================================
 namespace tmf {
 
 constexpr int FBM = 128, FBN = 128, FBK = 32, FLD = FBN + 1, FCAP = 16, FMAXK = 64;
+constexpr int FCAND_PEND = 0, FCAND_INS = 1;   // candidate handling of k_predict_topk: pending buffers + rare merges, or immediate insertion
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 2: K % 4 == 0 and V < 4 GB (buffer loads, constant per-thread offsets), 1: K % 4 == 0 (branch-free), 0: any K
-template <int NCH, int MODE>  // K_PAD = 32 * NCH
+// OR of a per-lane word over the 64 lanes of a wave (every lane ends with the result): DPP quad permutes and row mirrors, then the
+// gfx950 half-row / half-wave swaps - six VALU steps instead of one ballot per bit.
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);  // row_mirror
+    auto r = __builtin_amdgcn_permlane16_swap((int)v, (int)v, false, false);
+    v = (unsigned)r[0] | (unsigned)r[1];
+    r = __builtin_amdgcn_permlane32_swap((int)v, (int)v, false, false);
+    return (unsigned)r[0] | (unsigned)r[1];
+}
+
+template <int NCH, int MODE, int CAND>  // K_PAD = 32 * NCH; CAND: how candidates reach the rows' sorted lists (FCAND_*)
 __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const float* __restrict__ A, const float* __restrict__ B,
                                                          int64_t m, int64_t n, int K, int64_t lda, int64_t ldb, int k,
                                                          int clamp, int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_val) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool PEND = CAND == FCAND_PEND;
     float* Bs = reinterpret_cast<float*>(smem_raw);          // [3][FBK][FLD]
+    // FCAND_PEND (k <= 12): thresholds, per-row pending buffers and [k][FBM] sorted lists, merged by one lane per row
     float* tau = Bs + 3 * FBK * FLD;                         // [FBM]
     int* cnt = reinterpret_cast<int*>(tau + FBM);            // [FBM]
     int* ovf = cnt + FBM;                                    // [4] (one word used)
     float* pend_v = reinterpret_cast<float*>(ovf + 4);       // [FCAP][FBM]
     int* pend_i = reinterpret_cast<int*>(pend_v + FCAP * FBM);
-    float* list_v = reinterpret_cast<float*>(pend_i + FCAP * FBM);  // [k][FBM]
-    int* list_i = reinterpret_cast<int*>(list_v + (size_t)k * FBM);
-
+    float* plist_v = reinterpret_cast<float*>(pend_i + FCAP * FBM);  // [k][FBM]
+    int* plist_i = reinterpret_cast<int*>(plist_v + (size_t)k * FBM);
+    float* list_v = Bs + 3 * FBK * FLD;                      // FCAND_INS: [FBM][k], every row's k best so far, sorted (value desc, index asc)
+    int* list_i = reinterpret_cast<int*>(list_v + (size_t)FBM * k);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int64_t row0 = (int64_t)blockIdx.x * FBM;
@@ -409,12 +435,16 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
             a[2 * q + 1] = h ? v.w : v.z;
         }
     }
-    for (int t = tid; t < FBM; t += 256) {
-        tau[t] = (row0 + t < m) ? -INFINITY : INFINITY;  // rows past m never accept anything
-        cnt[t] = 0;
-        for (int j = 0; j < k; ++j) { list_v[j * FBM + t] = -INFINITY; list_i[j * FBM + t] = 0x7fffffff; }
+    if constexpr (PEND) {
+        for (int t = tid; t < FBM; t += 256) {
+            tau[t] = (row0 + t < m) ? -INFINITY : INFINITY;  // rows past m never accept anything
+            cnt[t] = 0;
+            for (int j = 0; j < k; ++j) { plist_v[j * FBM + t] = -INFINITY; plist_i[j * FBM + t] = 0x7fffffff; }
+        }
+        if (tid == 0) ovf[0] = 0;
+    } else {
+        for (int t = tid; t < FBM * k; t += 256) { list_v[t] = -INFINITY; list_i[t] = 0x7fffffff; }
     }
-    if (tid == 0) ovf[0] = 0;
 
     // ---- staging: thread -> (item = tid/8 + 32 q, float4 #tid%8 of the 32-wide k-chunk) ----
     const int s_item = tid >> 3, s_k4 = tid & 7;
@@ -497,17 +527,20 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
     __syncthreads();
 
     f32x16 acc[4];  // the wave's 32 users x the tile's 4 x 32 items
-    // Thresholds of the 16 rows this lane holds accumulator elements of, kept in registers: tau only changes in
-    // merge_wave(), after which they are re-read.  The steady state of a tile is then 16 x (max of the row's four
-    // values, one compare) and ONE wave-uniform branch - the per-element tests, LDS traffic and atomics below run
-    // only for the rows whose maximum beats their threshold (10/t of them at tile t for k = 10).
+    // Thresholds of the 16 rows this lane holds accumulator elements of - the row's current k-th best (value, index) - live in
+    // REGISTERS only: row (q, h) belongs to accumulator element q of the 32 lanes with this h, and an insertion into that row
+    // refreshes exactly that register in those lanes.  The steady state of a tile is 16 x (max of the row's four values, one
+    // compare) and ONE wave-uniform branch.
     float tq[16];
-    auto load_tau = [&]() {
+    int tqi[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
-    };
-    load_tau();
+    for (int q = 0; q < 16; ++q) {
+        const bool live_row = row0 + 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h < m;
+        tq[q] = live_row ? -INFINITY : INFINITY;   // rows past m never accept anything
+        tqi[q] = live_row ? 0x7fffffff : -1;
+    }
     auto prefilter = [&]() -> unsigned {
+        // strict: an equal value can only beat the k-th entry through a lower index, and every entry of an earlier tile has one
         unsigned pass = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -517,6 +550,69 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
         }
         return pass;
     };
+    // Insert (v, ix) into the sorted list of `row` (wave-uniform arguments) with all 64 lanes: lane j holds entry j, the
+    // candidate's position is the number of entries that rank before it (a prefix, by a ballot), everything behind moves
+    // down by one lane.  Two LDS reads and two writes, all conflict-free - no atomics, no pending buffer, no serial shifting
+    // (k = 64 costs what k = 10 costs).  Returns the row's new k-th entry.
+    auto insert = [&](int row, float v, int ix, float& kv, int& ki) {
+        float* Lv = list_v + row * k;
+        int* Li = list_i + row * k;
+        const bool in = lane < k;
+        const float mv = in ? Lv[lane] : INFINITY;       // lanes past k: "before everything", so they never count as movers
+        const int mi = in ? Li[lane] : -1;
+        const unsigned long long ahead = __builtin_amdgcn_ballot_w64(in && before(mv, mi, v, ix));
+        const int pos = __builtin_popcountll(ahead);     // entries that stay in front of the candidate
+        // entry of the lane below (DPP wave_shr:1 - no LDS round trip; lane 0 keeps its own value, which it never uses)
+        const float pv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mv), __float_as_int(mv), 0x138, 0xf, 0xf, false));
+        const int pi = __builtin_amdgcn_update_dpp(mi, mi, 0x138, 0xf, 0xf, false);
+        const float nv = lane < pos ? mv : (lane == pos ? v : pv);
+        const int ni = lane < pos ? mi : (lane == pos ? ix : pi);
+        if (in && lane >= pos) { Lv[lane] = nv; Li[lane] = ni; }
+        kv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nv), k - 1));
+        ki = __builtin_amdgcn_readlane(ni, k - 1);
+        wave_lds_sync();
+    };
+    auto take_candidates = [&](int64_t col0, unsigned pass) {
+        // ONE copy of the candidate code: the rows that have a candidate anywhere in the wave are walked by a wave-uniform q
+        // (register-indexed reads of the accumulators, thresholds and lists) - sixteen unrolled copies of the insertion pushed
+        // the kernel past the instruction cache.
+        unsigned rows_hit = __builtin_amdgcn_readfirstlane(wave_or(pass));
+        while (rows_hit) {
+            const int q = __builtin_ctz(rows_hit);
+            rows_hit &= rows_hit - 1;
+            const bool mine = (pass >> q) & 1u;
+            float tv = tq[q];
+            int ti = tqi[q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[j][q];
+                if (clamp) v = (v > 0.f) ? v : 0.f;
+                const int ix = (int)(col0 + 32 * j + l31);
+                bool c = mine && (col0 + 32 * j + l31 < n) && before(v, ix, tv, ti);
+                unsigned long long mask = __builtin_amdgcn_ballot_w64(c);
+                while (mask) {   // wave-uniform: one candidate per turn, lowest lane first
+                    const int src = __builtin_ctzll(mask);
+                    const float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+                    const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * (src >> 5);
+                    float kv;
+                    int ki;
+                    insert(row, cv, (int)(col0 + 32 * j + (src & 31)), kv, ki);
+                    if (h == (src >> 5)) { tv = kv; ti = ki; }            // the lanes that hold this row
+                    c = c && lane != src && before(v, ix, tv, ti);         // the others re-check against the new threshold
+                    mask = __builtin_amdgcn_ballot_w64(c);
+                }
+            }
+            tqi[q] = ti;
+            tq[q] = tv;
+        }
+    };
+
+    // ---- FCAND_PEND: append to pending buffers, merge rarely (round-1 / round-2 path; fastest for k <= 12) ----
+    auto load_tau = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
+    };
+    if constexpr (PEND) load_tau();
     auto offer = [&](int64_t col0, int group, unsigned pass) {
         // group < 0: every column; otherwise only local columns [16 group, 16 group + 16)
         // (a ballot + popcount slot assignment instead of the LDS atomic was measured slower: it makes all 64 lanes walk
@@ -547,23 +643,23 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
                 const float v = pend_v[p * FBM + row];
                 const int ix = pend_i[p * FBM + row];
                 int j = k - 1;
-                if (before(v, ix, list_v[j * FBM + row], list_i[j * FBM + row])) {
-                    while (j > 0 && before(v, ix, list_v[(j - 1) * FBM + row], list_i[(j - 1) * FBM + row])) {
-                        list_v[j * FBM + row] = list_v[(j - 1) * FBM + row];
-                        list_i[j * FBM + row] = list_i[(j - 1) * FBM + row];
+                if (before(v, ix, plist_v[j * FBM + row], plist_i[j * FBM + row])) {
+                    while (j > 0 && before(v, ix, plist_v[(j - 1) * FBM + row], plist_i[(j - 1) * FBM + row])) {
+                        plist_v[j * FBM + row] = plist_v[(j - 1) * FBM + row];
+                        plist_i[j * FBM + row] = plist_i[(j - 1) * FBM + row];
                         --j;
                     }
-                    list_v[j * FBM + row] = v;
-                    list_i[j * FBM + row] = ix;
+                    plist_v[j * FBM + row] = v;
+                    plist_i[j * FBM + row] = ix;
                 }
             }
             cnt[row] = 0;
-            if (row0 + row < m) tau[row] = list_v[(k - 1) * FBM + row];
+            if (row0 + row < m) tau[row] = plist_v[(k - 1) * FBM + row];
         }
     };
 
     int64_t g = 0;
-    int c_prev = 0;  // lanes h == 0: pending entries of the lane's row that predate the current tile
+    int c_prev = 0;  // FCAND_PEND, lanes h == 0: pending entries of the lane's row that predate the current tile
     for (int64_t tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -598,60 +694,86 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
             }
             __syncthreads();
         }
-        // top-k update: the 32 rows of a wave are touched by that wave only (pending lists, thresholds, sorted
-        // lists), so this part needs no workgroup barrier - LDS operations of one wave complete in order.
-        const int64_t col0 = tile * FBN;
-        const unsigned pass = prefilter();
-        if (__any(pass != 0u)) {  // wave-uniform
-            // Candidates are only APPENDED to the row's pending buffer here; the sorted lists (and with them the
-            // thresholds) are brought up to date when some row of the wave has filled half of its buffer.  A stale
-            // threshold is a lower bound of the true one, so nothing is lost - a few more candidates are appended and
-            // rejected by the merge - while the serial, LDS-latency-bound insertion runs ~20 times per row block
-            // instead of on most tiles.
-            offer(col0, -1, pass);
-            const int my_row = 32 * wave + l31;
-            const int c_now = (h == 0) ? cnt[my_row] : 0;
-            if (__any(c_now > FCAP)) {
-                // overflow: drop this tile's partial appends (keep the older ones), merge, then re-offer the tile in
-                // 8 groups of 16 columns with a merge after each (thresholds only rise: `pass` stays a superset)
-                if (h == 0) cnt[my_row] = c_prev;
-                merge_wave();
-                for (int grp = 0; grp < FBN / 16; ++grp) {
-                    offer(col0, grp, pass);
+        // top-k update: the 32 rows of a wave are touched by that wave only (sorted lists in LDS, thresholds in registers), so
+        // this part needs no workgroup barrier - LDS operations of one wave complete in order.
+        if constexpr (PEND) {
+            const int64_t col0 = tile * FBN;
+            const unsigned pass = prefilter();
+            if (__any(pass != 0u)) {  // wave-uniform
+                // Candidates are only APPENDED to the row's pending buffer here; the sorted lists (and with them the
+                // thresholds) are brought up to date when some row of the wave has filled half of its buffer.  A stale
+                // threshold is a lower bound of the true one, so nothing is lost - a few more candidates are appended and
+                // rejected by the merge - while the serial, LDS-latency-bound insertion runs ~20 times per row block
+                // instead of on most tiles.
+                offer(col0, -1, pass);
+                const int my_row = 32 * wave + l31;
+                const int c_now = (h == 0) ? cnt[my_row] : 0;
+                if (__any(c_now > FCAP)) {
+                    // overflow: drop this tile's partial appends (keep the older ones), merge, then re-offer the tile in
+                    // 8 groups of 16 columns with a merge after each (thresholds only rise: `pass` stays a superset)
+                    if (h == 0) cnt[my_row] = c_prev;
                     merge_wave();
+                    for (int grp = 0; grp < FBN / 16; ++grp) {
+                        offer(col0, grp, pass);
+                        merge_wave();
+                    }
+                    c_prev = 0;
+                    load_tau();
+                } else if (__any(c_now > FCAP / 2)) {
+                    merge_wave();
+                    c_prev = 0;
+                    load_tau();
+                } else {
+                    c_prev = c_now;
                 }
-                c_prev = 0;
-                load_tau();
-            } else if (__any(c_now > FCAP / 2)) {
-                merge_wave();
-                c_prev = 0;
-                load_tau();
-            } else {
-                c_prev = c_now;
+            }
+
+        } else {
+            const unsigned pass = prefilter();
+            if (__builtin_amdgcn_ballot_w64(pass != 0u) != 0) take_candidates(tile * FBN, pass);   // wave-uniform
+        }
+    }
+    if constexpr (PEND) merge_wave();  // whatever is still pending
+    __syncthreads();
+    if constexpr (PEND) {
+        if (tid < FBM && row0 + tid < m) {
+            for (int j = 0; j < k; ++j) {
+                out_idx[(row0 + tid) * k + j] = plist_i[j * FBM + tid];
+                if (out_val) out_val[(row0 + tid) * k + j] = plist_v[j * FBM + tid];
             }
         }
-    }
-    merge_wave();  // whatever is still pending
-    __syncthreads();
-    if (tid < FBM && row0 + tid < m) {
-        for (int j = 0; j < k; ++j) {
-            out_idx[(row0 + tid) * k + j] = list_i[j * FBM + tid];
-            if (out_val) out_val[(row0 + tid) * k + j] = list_v[j * FBM + tid];
+    } else {
+        // the lists are [row][k] like the output: one coalesced copy
+        const int64_t live = (m - row0 < FBM) ? m - row0 : FBM;
+        for (int64_t t = tid; t < live * k; t += 256) {
+            out_idx[row0 * k + t] = list_i[t];
+            if (out_val) out_val[row0 * k + t] = list_v[t];
         }
     }
+}
+
+template <int NCH, int MODE, int CAND>
+static int launch_predict_topk_mode(const float* A, const float* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
+                               int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
+    const size_t lds = CAND == FCAND_PEND ? sizeof(float) * (3 * FBK * FLD + FBM) + sizeof(int) * (FBM + 4) + 8 * (size_t)FCAP * FBM + 8 * (size_t)k * FBM
+                       : sizeof(float) * (3 * FBK * FLD) + 8 * (size_t)k * FBM;
+    static LdsGrant grant;  // per template instance
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk<NCH, MODE, CAND>), lds, grant)) return rc;
+    const int64_t blocks = (m + FBM - 1) / FBM;
+    hipLaunchKernelGGL((k_predict_topk<NCH, MODE, CAND>), dim3((unsigned)blocks), dim3(256), lds, stream, A, B, m, n, K, lda, ldb, k,
+                       clamp, out_idx, out_val);
+    return check_launch("tmf_predict_topk_f32");
 }
 
 template <int NCH, int MODE>
 static int launch_predict_topk_impl(const float* A, const float* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
                                int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (3 * FBK * FLD + FBM) + sizeof(int) * (FBM + 4) + 8 * (size_t)FCAP * FBM +
-                       8 * (size_t)k * FBM;
-    static LdsGrant grant;  // per template instance
-    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk<NCH, MODE>), lds, grant)) return rc;
-    const int64_t blocks = (m + FBM - 1) / FBM;
-    hipLaunchKernelGGL((k_predict_topk<NCH, MODE>), dim3((unsigned)blocks), dim3(256), lds, stream, A, B, m, n, K, lda, ldb, k,
-                       clamp, out_idx, out_val);
-    return check_launch("tmf_predict_topk_f32");
+    // same box, r = 128, TF by k (pending + merge / insertion): 10: 118.5 / 115.3   16: 89.9 / 110.0   24: 77.1 / 103.6
+    // 32: 65.9 / 75.7   48: 48.3 / 67.3   64: 36.4 / 61.1 (profiles/r03_predict_candidates.txt)
+    int cand = k <= 12 ? FCAND_PEND : FCAND_INS;
+    if (const char* env = getenv("TMF_PREDICT_CAND")) cand = atoi(env) ? FCAND_INS : FCAND_PEND;   // A/B runs
+    if (cand == FCAND_PEND) return launch_predict_topk_mode<NCH, MODE, FCAND_PEND>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
+    return launch_predict_topk_mode<NCH, MODE, FCAND_INS>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
 }
 
 template <int NCH>
