@@ -6,7 +6,8 @@ Rank 0 also runs the single-process fit and writes the comparison as JSON.
 With a third argument q >= 1 the ranks run the item-row-sharded fit instead (model.shard_items = q windows per rank:
 dist.ItemShardedEpoch - window broadcasts, per-window reduce into the owner), compared with the same single-process fit.
 
-env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT;  usage: python tools/dp_rehearsal.py OUT.json [loss] [q]"""
+env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT; TMF_REHEARSE_NCCL=1: one GPU per rank and an nccl (RCCL) group instead - no longer
+a rehearsal.  usage: python tools/dp_rehearsal.py OUT.json [loss] [q]"""
 import json
 import os
 import sys
@@ -27,7 +28,13 @@ def main():
     out, loss = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'wmrb')
     shard = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if os.environ.get('TMF_REHEARSE_NCCL') == '1':
+        # the real thing on a box with one GPU per rank: RCCL collectives, nothing staged through the host (the asynchronous
+        # all-gather / reduce-scatter branch of dist.ItemShardedEpoch, the in-place all-gather of dist.DataParallelEpoch)
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     rng = np.random.default_rng(7)
     m, n, r, S, lr, epochs = 3001, 701, 64, 48, 0.05, 3      # n not a multiple of world: V is padded
     deg = np.minimum(rng.zipf(1.6, m), n // 2)                 # skewed users: the partition is by cost, not by count
