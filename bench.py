@@ -411,7 +411,12 @@ class Workload:
                                             csc=loss == 'mse')
         self.wplan, self.R = None, None
         if loss == 'wmrb':
-            self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
+            if strong and world > 1:
+                # the ONE problem: its negative table is the table of the N = 1 run (seed 100), of which this rank keeps its users' rows
+                b, e = self.user_block
+                self.R = random_sampler_device(n, args.users, S, seed=100, device=dev)[b:e].contiguous()
+            else:
+                self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
             ns, sliced = _engine.choose_wmrb_user_pass(m, n, _lib.padded_ld(r, torch.bfloat16) if dtype == 'bf16' else ld, S, self.plan.n_pos, r,
                                                        elem_size=2 if dtype == 'bf16' else 4)
             rows4 = _engine.rows4_wanted(r, torch.bfloat16 if dtype == 'bf16' else torch.float32, self.plan, self.R)
