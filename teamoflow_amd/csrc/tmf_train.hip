@@ -11,6 +11,7 @@ namespace tmf {
 
 constexpr int kWavesPerBlock = 2;   // independent waves, no barrier; 2 per workgroup measured best (C4 item pass 32.1 ms; 4: 32.5, 8: 36.6; MSE epoch 11.1 vs 11.45)
 constexpr int kUnroll = 4;          // list entries a group keeps in flight
+constexpr int64_t kMaxBlocks = ((int64_t)1 << 32) / (64 * kWavesPerBlock) - 1;   // workgroups of one launch: < 2^32 work-items
 
 struct SegView {
     const int64_t* rowptr;
@@ -20,6 +21,7 @@ struct SegView {
     int64_t nseg;
     int32_t chunk;
     int32_t row_mod;  // > 0: list rows are (block * row_mod + table row); 0: list row == table row
+    int64_t seg0;     // first segment of this launch (a launch carries < 2^32 work-items: long segment lists go out in pieces)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
     float* __restrict__ slab, float* __restrict__ loss_part, int epi, tmf_adam adam) {
     constexpr int NG = 64 / G;
     const int lane = threadIdx.x & 63;
-    const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t seg = sv.seg0 + (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (seg >= sv.nseg) return;
     const int g = lane & (G - 1), grp = lane / G;
     const int lrow = sv.seg_row[seg];
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
     __shared__ int s_ids[kWavesPerBlock][kWsumTile];
     __shared__ float s_w[kWavesPerBlock][kWsumTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const int64_t seg = sv.seg0 + (int64_t)blockIdx.x * kWavesPerBlock + wave;
     if (seg >= sv.nseg) return;
     const int g = lane & (G - 1), grp = lane / G;
     const int row = sv.seg_row[seg];
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
     __shared__ float s_w[kWavesPerBlock][kWsumTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane & (G - 1), grp = lane / G;
-    const int64_t seg = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * NG + grp;
+    const int64_t seg = sv.seg0 + ((int64_t)blockIdx.x * kWavesPerBlock + wave) * NG + grp;
     const bool live = seg < sv.nseg;
     const int row = live ? sv.seg_row[seg] : 0;
     int64_t beg = 0, end = 0;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(1024) void k_sum_f32(const float* __restrict__ x, i
 }
 
 static inline SegView view(const tmf_segments* s) {
-    return SegView{s->rowptr, s->seg_row, s->seg_chunk, s->seg_slab, s->nseg, s->chunk, s->row_mod};
+    return SegView{s->rowptr, s->seg_row, s->seg_chunk, s->seg_slab, s->nseg, s->chunk, s->row_mod, 0};
 }
 
 static int check_segments(const tmf_segments* s) {
@@ -445,14 +447,18 @@ static int mse_pass_impl(const tmf_segments* seg, const int32_t* other, const fl
     TMF_REQUIRE(X_old && Y_old && X_out, "mse_pass: null table");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "mse_pass: bad epilogue %d", epi);
     const RowGeom geom = row_geom_of<T>(n_components);
-    const SegView sv = view(seg);
-    const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
-    TMF_REQUIRE_LAUNCH((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock, 64 * kWavesPerBlock, "mse_pass");
+    SegView sv = view(seg);
+    // a launch carries < 2^32 work-items (tmf::launch_fits): the segment list goes out in pieces of kMaxBlocks workgroups
+    for (sv.seg0 = 0; sv.seg0 < seg->nseg; sv.seg0 += kMaxBlocks * kWavesPerBlock) {
+        const int64_t left = seg->nseg - sv.seg0;
+        const int64_t want = (left + kWavesPerBlock - 1) / kWavesPerBlock;
+        const unsigned blocks = (unsigned)(want < kMaxBlocks ? want : kMaxBlocks);
 #define CALL(G_, NV_)                                                                                          \
     hipLaunchKernelGGL((k_mse_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
                        sv, other, val, (const T*)X_old, (const T*)Y_old, X_out, slab, loss_part, epi, adam)
-    TMF_DISPATCH(T, geom, CALL);
+        TMF_DISPATCH(T, geom, CALL);
 #undef CALL
+    }
     return check_launch("tmf_mse_pass");
 }
 
@@ -465,7 +471,7 @@ static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const
     TMF_REQUIRE(Tab && X_out && ent_row && ent_w && wbuf && (epi == TMF_EPI_GRAD || X_old), "wsum_pass: null pointer");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wsum_pass: bad epilogue %d", epi);
     const RowGeom geom = row_geom_of<T>(n_components);
-    const SegView sv = view(seg);
+    SegView sv = view(seg);
     {
         const char* env = getenv("TMF_WSUM_PER_GROUP");
         // ... and only when the segments still fill the chip at 64/G of them per wave (MovieLens-1M shape: 15K segments of
@@ -473,23 +479,27 @@ static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const
         const bool forced = env && env[0] == '1';
         if (!(env && env[0] == '0') && geom.G >= 16 && (forced || seg->nseg / (64 / geom.G) >= 16384)) {
             const int64_t per_block = (int64_t)kWavesPerBlock * (64 / geom.G);
-            const unsigned pblocks = (unsigned)((seg->nseg + per_block - 1) / per_block);
-            TMF_REQUIRE_LAUNCH((seg->nseg + per_block - 1) / per_block, 64 * kWavesPerBlock, "wsum_pass");
+            for (sv.seg0 = 0; sv.seg0 < seg->nseg; sv.seg0 += kMaxBlocks * per_block) {   // pieces of < 2^32 work-items
+                const int64_t want = (seg->nseg - sv.seg0 + per_block - 1) / per_block;
+                const unsigned pblocks = (unsigned)(want < kMaxBlocks ? want : kMaxBlocks);
 #define CALLPG(G_, NV_)                                                                                               \
     hipLaunchKernelGGL((k_wsum_pass_pg<G_, NV_, T>), dim3(pblocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
                        sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
-            TMF_DISPATCH(T, geom, CALLPG);
+                TMF_DISPATCH(T, geom, CALLPG);
 #undef CALLPG
+            }
             return check_launch("tmf_wsum_pass (per group)");
         }
     }
-    const unsigned blocks = (unsigned)((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock);
-    TMF_REQUIRE_LAUNCH((seg->nseg + kWavesPerBlock - 1) / kWavesPerBlock, 64 * kWavesPerBlock, "wsum_pass");
+    for (sv.seg0 = 0; sv.seg0 < seg->nseg; sv.seg0 += kMaxBlocks * kWavesPerBlock) {   // pieces of < 2^32 work-items
+        const int64_t want = (seg->nseg - sv.seg0 + kWavesPerBlock - 1) / kWavesPerBlock;
+        const unsigned blocks = (unsigned)(want < kMaxBlocks ? want : kMaxBlocks);
 #define CALL(G_, NV_)                                                                                           \
     hipLaunchKernelGGL((k_wsum_pass<G_, NV_, T>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream, \
                        sv, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, slab, epi, adam)
-    TMF_DISPATCH(T, geom, CALL);
+        TMF_DISPATCH(T, geom, CALL);
 #undef CALL
+    }
     return check_launch("tmf_wsum_pass");
 }
 

@@ -258,3 +258,37 @@ def test_slice_grids_beyond_one_launch(tm, monkeypatch):  # noqa: F811
         assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], lr, what=f'V xcd={xcd} rs={rs}', slack=sl['gV'])
         del model
         torch.cuda.empty_cache()
+
+
+def test_segment_lists_beyond_one_launch(tm):  # noqa: F811
+    """The row passes launch one wave per list segment, two waves per workgroup: beyond 2^32 / 64 = 67.1M segments a single launch
+    would exceed 2^32 work-items (the config-5 shard reaches that with more than ~130 user blocks x 1M items).  68M users with one
+    interaction each: the MSE user pass goes out in two pieces; loss and sampled rows - first, last, and around the seam -
+    against fp64 on the GPU."""
+    dev = torch.device('cuda', 0)
+    m, n, r, lr = 68_000_000, 1000, 4, 0.01
+    g = torch.Generator(device=dev).manual_seed(3)
+    u = torch.arange(m, device=dev)
+    idx = torch.stack([u, u % n], dim=1)
+    val = torch.randint(1, 6, (m,), device=dev, generator=g).to(torch.float32)
+    U0 = torch.randn(m, r, device=dev, generator=g) * 0.3
+    V0 = torch.randn(n, r, device=dev, generator=g) * 0.3
+    plan = tm.engine.InteractionPlan(idx, val, m, n, csc=True)
+    assert plan.seg_u.nseg == m > (1 << 32) // 64
+    st = tm.engine.TrainState(U0, V0, plan, r)
+    adam = tm.engine.adam_constants(lr)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    tm.engine.epoch_mse(st, adam, loss)
+    torch.cuda.synchronize()
+    p = (U0.double() * V0.double()[u % n]).sum(1)
+    err = val.double() - p
+    assert abs(float(loss[0]) - float((err * err).sum())) <= 1e-6 * float((err * err).sum())
+    seam = (((1 << 32) // 128) - 1) * 2          # first segment of the second launch piece
+    rows = torch.tensor([0, 1, 12345, seam - 2, seam - 1, seam, seam + 1, m - 2, m - 1], device=dev)
+    gU = (-2.0 * err[rows])[:, None] * V0.double()[rows % n]
+    assert_step(st.U_nxt[rows, :r].cpu().numpy(), U0[rows].cpu().numpy(), gU.cpu().numpy(), lr, what='users around the launch seam')
+    # the item side (1000 rows of 68000 entries each = 67 segments per row + combine) sees every user once
+    j = 7
+    sel = torch.arange(j, m, n, device=dev)
+    gV = ((-2.0 * err[sel])[:, None] * U0.double()[sel]).sum(0)
+    assert_step(st.V_nxt[j:j + 1, :r].cpu().numpy(), V0[j:j + 1].cpu().numpy(), gV[None].cpu().numpy(), lr, what='item row')
