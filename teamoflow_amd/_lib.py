@@ -126,7 +126,12 @@ def load_library():
                                 f'or `make -C {CSRC}`')
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if os.environ.get('TMF_LIB_OLDER') == '1':   # A/B runs against a library built from an older commit (tools/c4_ab.sh)
+                continue
+            raise
         fn.restype, fn.argtypes = res, args
     if lib.tmf_version() < 201:
         raise EngineUnavailable('libtmf.so is older than this package')

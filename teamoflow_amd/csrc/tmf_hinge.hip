@@ -125,10 +125,22 @@ __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
         wave_lds_sync();
         // rank sort: position of entry i = #{ j : key_j < key_i } (keys are distinct)
         int rank[4] = {0, 0, 0, 0};
-        for (int j = 0; j < len; ++j) {
-            const unsigned long long kj = L.keys[j];  // same address in every lane: broadcast
+        // only the key slots the chunk populates are ranked (entry i = lane + 64 q < len): a chunk of <= 64 / <= 128 entries -
+        // most users - compares one / two keys per step instead of four (wave-uniform choice of the loop)
+        if (len <= 64) {
+            for (int j = 0; j < len; ++j) rank[0] += (L.keys[j] < kq[0]) ? 1 : 0;   // same address in every lane: broadcast
+        } else if (len <= 128) {
+            for (int j = 0; j < len; ++j) {
+                const unsigned long long kj = L.keys[j];
+                rank[0] += (kj < kq[0]) ? 1 : 0;
+                rank[1] += (kj < kq[1]) ? 1 : 0;
+            }
+        } else {
+            for (int j = 0; j < len; ++j) {
+                const unsigned long long kj = L.keys[j];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rank[q] += (kj < kq[q]) ? 1 : 0;
+                for (int q = 0; q < 4; ++q) rank[q] += (kj < kq[q]) ? 1 : 0;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
