@@ -22,6 +22,7 @@ struct SegView {
     int32_t chunk;
     int32_t row_mod;  // > 0: list rows are (block * row_mod + table row); 0: list row == table row
     int64_t seg0;     // first segment of this launch (a launch carries < 2^32 work-items: long segment lists go out in pieces)
+    int xcd_run;      // k_wsum_pass_pg: consecutive workgroups per XCD run (0 = plain block order)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -180,7 +181,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
     __shared__ float s_w[kWavesPerBlock][kWsumTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane & (G - 1), grp = lane / G;
-    const int64_t seg = sv.seg0 + ((int64_t)blockIdx.x * kWavesPerBlock + wave) * NG + grp;
+    // XCD-contiguous block order (sv.xcd_run > 0; speed only): blocks b and b + 8 share an XCD under the observed round-robin
+    // placement, so XCD x is given RUNS of xcd_run consecutive workgroups (= consecutive lists of one user block) instead of every
+    // eighth one - neighbouring lists gather their 4-byte weights from the same lines of D (a 64-byte line of a user's row holds
+    // the weights of 16 items that lie ~1,500 item ids apart at C4), which then meet in ONE L2 instead of eight.
+    int64_t blk = blockIdx.x;
+    if (sv.xcd_run > 0) {
+        const int64_t super = (int64_t)8 * sv.xcd_run, full = (int64_t)gridDim.x / super * super;
+        if (blk < full) {
+            const int64_t sc = blk / super, r = blk % super;
+            blk = sc * super + (r & 7) * sv.xcd_run + (r >> 3);
+        }
+    }
+    const int64_t seg = sv.seg0 + (blk * kWavesPerBlock + wave) * NG + grp;
     const bool live = seg < sv.nseg;
     const int row = live ? sv.seg_row[seg] : 0;
     int64_t beg = 0, end = 0;
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_sum_f32(const float* __restrict__ x, i
 }
 
 static inline SegView view(const tmf_segments* s) {
-    return SegView{s->rowptr, s->seg_row, s->seg_chunk, s->seg_slab, s->nseg, s->chunk, s->row_mod, 0};
+    return SegView{s->rowptr, s->seg_row, s->seg_chunk, s->seg_slab, s->nseg, s->chunk, s->row_mod, 0, 0};
 }
 
 static int check_segments(const tmf_segments* s) {
@@ -479,6 +492,11 @@ static int wsum_pass_impl(const tmf_segments* seg, const int32_t* ent_row, const
         const bool forced = env && env[0] == '1';
         if (!(env && env[0] == '0') && geom.G >= 16 && (forced || seg->nseg / (64 / geom.G) >= 16384)) {
             const int64_t per_block = (int64_t)kWavesPerBlock * (64 / geom.G);
+            // XCD runs of 512 workgroups (2048 lists) when the pass has at least a few super-chunks of them.  Same box, C4 fp32 item
+            // pass ms by run length: 0 (plain order) 31.8 - 32.0, 64: 31.6, 128: 31.1, 256: 30.7 - 30.9, 384: 30.7, 512: 30.7,
+            // 1024: 30.9, 2048: 31.4, 8192: 32.0 (profiles/r03_c5_experiments.txt item 8).  TMF_WSUM_XCD_RUN overrides (A/B runs).
+            sv.xcd_run = (seg->nseg / per_block >= 4 * 8 * 512) ? 512 : 0;
+            if (const char* xr = getenv("TMF_WSUM_XCD_RUN")) sv.xcd_run = atoi(xr);
             for (sv.seg0 = 0; sv.seg0 < seg->nseg; sv.seg0 += kMaxBlocks * per_block) {   // pieces of < 2^32 work-items
                 const int64_t want = (seg->nseg - sv.seg0 + per_block - 1) / per_block;
                 const unsigned pblocks = (unsigned)(want < kMaxBlocks ? want : kMaxBlocks);
