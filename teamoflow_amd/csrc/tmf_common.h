@@ -163,6 +163,8 @@ struct RowMap<G, NV, __bf16> {
     static __device__ __forceinline__ int off(int v, int g) { return 8 * (g + G * (v >> 1)) + 4 * (v & 1); }
 };
 
+typedef float tmf_f4 __attribute__((ext_vector_type(4)));
+
 template <int G, int NV>
 __device__ __forceinline__ void load_row(Frag<NV>& f, const float* __restrict__ T, int64_t row, int g) {
     const float4* p = reinterpret_cast<const float4*>(T + row * (int64_t)(4 * G * NV)) + g;
@@ -241,7 +243,6 @@ __device__ __forceinline__ void to_frag(Frag<NV>& f, const Raw<NV, __bf16>& r) {
 // ISA of k_wsum_pass for `global_load_dwordx4` directly followed by `s_waitcnt vmcnt(0)` after touching this file
 // (profiles/r01_sliced_user_pass.txt has the same-box numbers, including the variant that loads into raw registers and
 // converts / selects afterwards in every gather loop: slower on C4, 3 % faster on the config-5 shard - not kept).
-typedef float tmf_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_f4_nt(float* p, const float4& v) {
     const tmf_f4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<tmf_f4*>(p));
@@ -266,11 +267,23 @@ __device__ __forceinline__ void store_row(const Frag<NV>& f, __bf16* __restrict_
     }
 }
 
-template <int G, int NV, typename T>
+// Partial rows (slab slots, per-slice layers) are written once and read once by the kernel that sums them: that read carries the
+// non-temporal hint too (combine 1.42 -> 1.30 ms, finish 1.30 -> 1.28 at C4; the same hint on slice offsets or on the hinge
+// kernel's score loads changed nothing, on the item pass's entry lists it cost 2 ms - profiles/r03_c5_experiments.txt item 10).
+#ifndef TMF_NT_FIN
+#define TMF_NT_FIN 1
+#endif
+__device__ __forceinline__ float4 load_f4_nt(const float* p) {
+    const tmf_f4 t = __builtin_nontemporal_load(reinterpret_cast<const tmf_f4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+template <int G, int NV, typename T, bool NT = false>
 __device__ __forceinline__ void load_row_f32(Frag<NV>& f, const float* __restrict__ B, int64_t row, int g) {
     const float* p = B + row * (int64_t)(4 * G * NV);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) f.v[v] = *reinterpret_cast<const float4*>(p + RowMap<G, NV, T>::off(v, g));
+    for (int v = 0; v < NV; ++v)
+        f.v[v] = NT ? load_f4_nt(p + RowMap<G, NV, T>::off(v, g)) : *reinterpret_cast<const float4*>(p + RowMap<G, NV, T>::off(v, g));
 }
 
 template <int G, int NV, typename T>

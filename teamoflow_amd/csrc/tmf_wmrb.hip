@@ -372,6 +372,12 @@ static int launch_wmrb_user(const int64_t* rowptr, const int32_t* col, const flo
 // (An in-launch variant - scores + hinge in one launch behind an agent-scope ticket - was measured slower and
 // removed; see profiles/r01_sliced_user_pass.txt.)
 // ---------------------------------------------------------------------------------------------
+#ifndef TMF_STREAM_NT
+#define TMF_STREAM_NT 1
+#endif
+// Read-once streams (ids, weights of a (user, slice) range) are loaded with the non-temporal hint, so that they do not displace
+// the slice's V rows in the L2s: same box, C4 fp32, gradU 26.6 -> 25.0 ms, scores 27.9 -> 27.75 (profiles/r03_c5_experiments.txt item 10)
+constexpr bool kStreamNT = TMF_STREAM_NT;
 constexpr int kSliceUsers = 16;   // users per workgroup of the slice kernels (SliceLists::upg)
 // Waves per workgroup of the slice kernels: 4, or 8 when a (user, slice) range is long (C4 fp32: 86 rows).  With 512-byte rows
 // eight waves are 16 lane groups = ONE user per lane group, and the workgroup retires when its users are done.  Same box,
@@ -400,8 +406,8 @@ __device__ __forceinline__ void slice_list(int* ids, float* dst, const int32_t* 
     for (int t0 = beg; t0 < end; t0 += kStageTile) {
         const int cnt = (end - t0 < kStageTile) ? end - t0 : kStageTile;
         for (int e = g; e < cnt; e += G) {
-            ids[e] = list[t0 + e];
-            if (GRADU) dst[e] = wts[t0 + e];
+            ids[e] = kStreamNT ? __builtin_nontemporal_load(list + t0 + e) : list[t0 + e];
+            if (GRADU) dst[e] = kStreamNT ? __builtin_nontemporal_load(wts + t0 + e) : wts[t0 + e];
         }
         wave_lds_sync();
         float keep = 0.f;  // scores: lane g keeps the score of entry (e & (G-1)) == g until G of them are complete
@@ -729,10 +735,10 @@ __global__ __launch_bounds__(kThreads) void k_wmrb_finish(const float* part, int
     const int64_t u = (int64_t)blockIdx.x * NGB + (threadIdx.x >> 6) * NG + lane / G;
     if (u >= n_users) return;
     Frag<NV> acc;
-    load_row_f32<G, NV, T>(acc, part, u, g);
+    load_row_f32<G, NV, T, TMF_NT_FIN>(acc, part, u, g);
     for (int sl = 1; sl < n_slices; ++sl) {
         Frag<NV> y;
-        load_row_f32<G, NV, T>(y, part, sl * n_users + u, g);
+        load_row_f32<G, NV, T, TMF_NT_FIN>(y, part, sl * n_users + u, g);
         add<NV>(acc, y);
     }
     row_epilogue<G, NV, T>(acc, U_old, U_out, u, g, epi, adam);
