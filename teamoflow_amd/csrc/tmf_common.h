@@ -164,6 +164,10 @@ struct RowMap<G, NV, __bf16> {
 };
 
 typedef float tmf_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_f4_nt(const float* p) {
+    const tmf_f4 t = __builtin_nontemporal_load(reinterpret_cast<const tmf_f4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
 
 template <int G, int NV>
 __device__ __forceinline__ void load_row(Frag<NV>& f, const float* __restrict__ T, int64_t row, int g) {
@@ -178,6 +182,25 @@ __device__ __forceinline__ void load_row(Frag<NV>& f, const __bf16* __restrict__
 #pragma unroll
     for (int pv = 0; pv < NV / 2; ++pv) {
         const f32x8 w = __builtin_convertvector(p[G * pv], f32x8);
+        f.v[2 * pv] = make_float4(w[0], w[1], w[2], w[3]);
+        f.v[2 * pv + 1] = make_float4(w[4], w[5], w[6], w[7]);
+    }
+}
+
+// A row that is read ONCE by the kernel (the user's own row of a (user, slice) visit): non-temporal, so that it does not displace
+// the rows the kernel gathers again and again in the L2s (scores 27.5 -> 26.9 ms at C4).
+template <int G, int NV>
+__device__ __forceinline__ void load_row_nt(Frag<NV>& f, const float* __restrict__ T, int64_t row, int g) {
+    const float* p = T + row * (int64_t)(4 * G * NV) + 4 * g;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) f.v[v] = load_f4_nt(p + 4 * G * v);
+}
+template <int G, int NV>
+__device__ __forceinline__ void load_row_nt(Frag<NV>& f, const __bf16* __restrict__ T, int64_t row, int g) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(T + row * (int64_t)(4 * G * NV)) + g;
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv) {
+        const f32x8 w = __builtin_convertvector(__builtin_nontemporal_load(p + G * pv), f32x8);
         f.v[2 * pv] = make_float4(w[0], w[1], w[2], w[3]);
         f.v[2 * pv + 1] = make_float4(w[4], w[5], w[6], w[7]);
     }
@@ -273,11 +296,6 @@ __device__ __forceinline__ void store_row(const Frag<NV>& f, __bf16* __restrict_
 #ifndef TMF_NT_FIN
 #define TMF_NT_FIN 1
 #endif
-__device__ __forceinline__ float4 load_f4_nt(const float* p) {
-    const tmf_f4 t = __builtin_nontemporal_load(reinterpret_cast<const tmf_f4*>(p));
-    return make_float4(t[0], t[1], t[2], t[3]);
-}
-
 template <int G, int NV, typename T, bool NT = false>
 __device__ __forceinline__ void load_row_f32(Frag<NV>& f, const float* __restrict__ B, int64_t row, int g) {
     const float* p = B + row * (int64_t)(4 * G * NV);

@@ -10,6 +10,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "tmf_common.h"
 
 namespace tmf {
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_scores3(SliceLists a, const
         const int nb = a.off[o], ne = a.off[o + 1], pb = a.poff[o], pe = a.poff[o + 1];
         if (nb == ne && pb == pe) continue;
         Frag<NV> x, none;
-        load_row<G, NV>(x, U, u, g);
+        load_row_nt<G, NV>(x, U, u, g);   // read once per (user, slice) visit
         slice_list<G, NV, T, false>(ids, dst, a.R + u * (int64_t)a.S, nb, ne, V, x, none, sp + u * (int64_t)a.S, nullptr, g,
                                     a.item_base);
         const int64_t rb = a.rowptr[u];
