@@ -1,4 +1,6 @@
 """Tensor-level wrappers over the predict / ranking entry points of libtmf.so."""
+import os
+
 import torch
 
 from . import _lib
@@ -43,6 +45,7 @@ def predict_gemm(user_embedding, item_embedding, out=None):
 
 
 FUSED_MAX_K, FUSED_MAX_K_BF16, FUSED_MAX_R, FUSED_MAX_R_BF16 = 64, 32, 256, 256
+SPLIT_BY_DEFAULT = False   # whether arithmetic='auto' takes the three-plane bf16 split where it applies
 SORT_MAX_ELEMS = 1 << 29   # elements ranked per call of the wide-row path (2 GB of keys + 2 GB of ids, twice)
 
 
@@ -64,11 +67,23 @@ def fused_topk_supported(user_embedding, item_embedding, k):
     return k <= (FUSED_MAX_K_BF16 if bf16 else FUSED_MAX_K) and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
 
 
-def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False):
+PREDICT_ARITHMETIC = os.environ.get('TMF_PREDICT_ARITHMETIC', 'auto')   # 'auto' | 'fp32' | 'split'
+
+
+def split_topk_supported(r, k):
+    return 1 <= r <= 128 and 1 <= k <= 32
+
+
+def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False, arithmetic=None):
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
-    fp32 tables: exact-fp32 MFMA, k <= 64, width <= 256.  bf16 tables (both operands): bf16 MFMA with fp32
-    accumulation, k <= 32, width <= 256.  See topk_stable(predict_gemm(...)) for the general case."""
+    fp32 tables: fp32 MFMA (k <= 64, width <= 256), or - arithmetic='split', width <= 128, k <= 32 - the fp32-accurate
+    three-plane bf16 split on the bf16 MFMA (tmf_predict_topk_split_f32); 'auto' takes the split kernel where it applies.
+    bf16 tables (both operands): bf16 MFMA with fp32 accumulation, k <= 32, width <= 256.
+    See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
+    arithmetic = arithmetic or PREDICT_ARITHMETIC
+    if arithmetic not in ('auto', 'fp32', 'split'):
+        raise ValueError(f"arithmetic={arithmetic!r}: expected 'auto', 'fp32' or 'split'")
     if torch.is_tensor(user_embedding) and torch.is_tensor(item_embedding) and \
             user_embedding.dtype == torch.bfloat16 and item_embedding.dtype == torch.bfloat16:
         A, m, r, lda = _bf16_operand(_cuda(user_embedding))
@@ -92,6 +107,14 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
         raise ValueError(f'k={k} must be in [1, {n}]')
     idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
+    if arithmetic == 'split' and not split_topk_supported(r, k):
+        raise ValueError(f'the split kernel supports widths <= 128 and k <= 32 (got {r}, {k})')
+    if arithmetic == 'split' or (arithmetic == 'auto' and SPLIT_BY_DEFAULT and split_topk_supported(r, k)):
+        need = lib.tmf_predict_topk_split_workspace_bytes(n, r)
+        ws = torch.empty(need, dtype=torch.uint8, device=A.device)
+        _lib.check(lib.tmf_predict_topk_split_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
+                                                  _lib.ptr(idx), _lib.ptr(vals), _lib.ptr(ws), need, _lib.stream_ptr()), lib)
+        return (vals, idx) if return_values else idx
     _lib.check(lib.tmf_predict_topk_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
                                         _lib.ptr(idx), _lib.ptr(vals), _lib.stream_ptr()), lib)
     return (vals, idx) if return_values else idx

@@ -1,0 +1,331 @@
+// Fused predict + stable top-k for fp32 factors on the bf16 matrix cores: every fp32 value is split EXACTLY into three bf16
+// planes (x = x1 + x2 + x3: 8 + 8 + 8 significant bits, round-to-nearest residuals), and <u, v> is the sum of the six
+// bf16 x bf16 products whose weight is not below 2^-24 of the leading one,
+//     u3 v1 + u1 v3 + u2 v2 + u2 v1 + u1 v2 + u1 v1          (small terms first inside every k-step),
+// each of them exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  The dropped products (u2 v3, u3 v2, u3 v3) are
+// <= 2^-24 relative per term - one fp32 rounding - so the result is an fp32-accurate dot product: measured against an fp64
+// reference the values are as close as (big terms first) or closer than (small terms first) those of the fp32 MFMA kernel
+// (tools/split_accuracy.py: max |err| / max |ref| 0.8e-7 ... 3.0e-7 against 2.4e-7 ... 3.1e-7).  Six bf16 MFMAs cost 6 / 16
+// of one fp32 MFMA of the same shape on gfx950 (2.5 PFLOP/s against 157 TFLOP/s dense), so the fp32-equivalent ceiling of
+// this kernel is 2.7 x the fp32 MFMA peak.
+//
+// Structure: that of k_predict_topk_bf16 (tmf_predict.hip).  512 threads = 8 waves own 256 users, 32 per wave; the users'
+// rows are split in registers at load time and stay there as A fragments of the three planes (3 x K/16 x 4 VGPRs per lane).
+// The item table is split once per call into a caller-provided workspace ([3][n_pad][32 NCH] bf16, zero padded), and item
+// tiles of 128 stream through a 2-slot LDS ring in k-chunks of 32: [plane][item][64 B of data + 16 B pad] - an 80-byte row
+// pitch puts 16 consecutive rows on 16 different 16-byte bank slots (5 i mod 16), so the ds_read_b128 operand reads are
+// conflict-free.  Per (k-step, 32-column block) a wave reads three B fragments and issues six MFMAs: half an LDS read per
+// MFMA, where the one-plane bf16 kernel needs one.  Candidates reach the rows' sorted lists as in the bf16 kernel
+// (per-row threshold in registers, pending buffer, one lane per row merges).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tmf.h"
+#include "tmf_common.h"
+
+namespace tmf {
+
+typedef float f32x16_s __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+typedef float f32x4_s __attribute__((ext_vector_type(4)));
+
+constexpr int SBM = 256, SBN = 128, SROW = 80 /* bytes */, SCAP = 16, SMAXK = 32, SMAXR = 128;
+constexpr int SPLANE = SBN * SROW, SSLOT = 3 * SPLANE;
+
+__device__ __forceinline__ bool before_s(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+// x -> (x1, x2, x3) with x1 + x2 + x3 == x exactly for every finite x whose residuals stay normal.  A value that rounds to
+// +-inf in bf16 is truncated instead; non-finite inputs keep their class in x1 and contribute nothing through x2, x3.
+__device__ __forceinline__ void split3(float x, __bf16& x1, __bf16& x2, __bf16& x3) {
+    __bf16 h = (__bf16)x;
+    if (__builtin_isinf((float)h) && !__builtin_isinf(x)) h = __builtin_bit_cast(__bf16, (uint16_t)(__float_as_uint(x) >> 16));
+    x1 = h;
+    if (!__builtin_isfinite(x)) { x2 = (__bf16)0.0f; x3 = (__bf16)0.0f; return; }
+    const float r1 = x - (float)h;
+    x2 = (__bf16)r1;
+    x3 = (__bf16)(r1 - (float)x2);
+}
+
+// Rows [0, rows_pad) x columns [0, ldp) of the three planes; everything outside [0, rows) x [0, r) is zero.
+__global__ __launch_bounds__(256) void k_split3_rows(const float* __restrict__ X, int64_t rows, int r, int64_t ld,
+                                                     __bf16* __restrict__ out, int64_t rows_pad, int ldp) {
+    const int groups = ldp / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows_pad * groups) return;
+    const int64_t row = t / groups;
+    const int c0 = (int)(t % groups) * 8;
+    bf16x8_s p1, p2, p3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (row < rows && c0 + e < r) ? X[row * ld + c0 + e] : 0.f;
+        __bf16 a, b, c;
+        split3(x, a, b, c);
+        p1[e] = a; p2[e] = b; p3[e] = c;
+    }
+    const int64_t plane = rows_pad * ldp, o = row * ldp + c0;
+    *reinterpret_cast<bf16x8_s*>(out + o) = p1;
+    *reinterpret_cast<bf16x8_s*>(out + plane + o) = p2;
+    *reinterpret_cast<bf16x8_s*>(out + 2 * plane + o) = p3;
+}
+
+template <int NCH>  // K_PAD = 32 * NCH
+__global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __restrict__ A, const __bf16* __restrict__ Bp,
+                                                               int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda, int k,
+                                                               int clamp, int32_t* __restrict__ out_idx,
+                                                               float* __restrict__ out_val) {
+    constexpr int LDP = 32 * NCH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* Bs = smem_raw;                                               // [2 slots][3 planes][SBN][SROW] bytes
+    float* tau = reinterpret_cast<float*>(Bs + 2 * SSLOT);             // [SBM]
+    int* cnt = reinterpret_cast<int*>(tau + SBM);                      // [SBM]
+    float* pend_v = reinterpret_cast<float*>(cnt + SBM);               // [SCAP][SBM]
+    int* pend_i = reinterpret_cast<int*>(pend_v + SCAP * SBM);
+    float* list_v = reinterpret_cast<float*>(pend_i + SCAP * SBM);     // [k][SBM]
+    int* list_i = reinterpret_cast<int*>(list_v + (size_t)k * SBM);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * SBM;
+
+    // A fragments of the three planes: a?[kk] = plane?(U[row0 + 32 wave + l31][16 kk + 8 h .. + 8))
+    bf16x8_s a1[2 * NCH], a2[2 * NCH], a3[2 * NCH];
+    {
+        const int64_t r = row0 + 32 * wave + l31;
+        const float* p = A + (r < m ? r : 0) * lda;
+#pragma unroll
+        for (int kk = 0; kk < 2 * NCH; ++kk) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.f;
+            const int k0 = 16 * kk + 8 * h;
+            if (r < m && k0 < K) {
+                if (k0 + 7 < K) {
+                    const f32x4_s lo = *reinterpret_cast<const f32x4_s*>(p + k0), hi = *reinterpret_cast<const f32x4_s*>(p + k0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+                } else {
+                    for (int e = 0; e < 8; ++e) if (k0 + e < K) x[e] = p[k0 + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 u, v, w;
+                split3(x[e], u, v, w);
+                a1[kk][e] = u; a2[kk][e] = v; a3[kk][e] = w;
+            }
+        }
+    }
+    for (int t = tid; t < SBM; t += 512) {
+        tau[t] = (row0 + t < m) ? -INFINITY : INFINITY;
+        cnt[t] = 0;
+        for (int j = 0; j < k; ++j) { list_v[j * SBM + t] = -INFINITY; list_i[j * SBM + t] = 0x7fffffff; }
+    }
+
+    // staging: thread -> (item tid / 4, 16-byte piece tid % 4 of the 64-byte k-chunk) of each plane
+    const int s_item = tid >> 2, s_slot = tid & 3;
+    const int64_t ntiles = (n + SBN - 1) / SBN;
+    const int64_t nchunks = ntiles * NCH;
+    const int64_t plane = n_pad * LDP;
+    const __bf16* src0 = Bp + (int64_t)s_item * LDP + 8 * s_slot;
+    bf16x8_s stg[3];     // chunk g + 1 on its way to LDS while chunk g is multiplied (48 MFMAs per wave: ~3000 cycles per chunk)
+    auto g_load = [&](int64_t g, bf16x8_s* stage) {
+        const int64_t gg = g < nchunks ? g : nchunks - 1;   // read-ahead past the last chunk re-reads it (never written to LDS use)
+        const __bf16* s = src0 + (gg / NCH) * (int64_t)SBN * LDP + 32 * (int)(gg % NCH);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) stage[p] = *reinterpret_cast<const bf16x8_s*>(s + p * plane);
+    };
+    auto s_write_from = [&](int slot, const bf16x8_s* src) {
+        char* dst = Bs + slot * SSLOT + s_item * SROW + s_slot * 16;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8_s*>(dst + p * SPLANE) = src[p];
+    };
+    g_load(0, stg); s_write_from(0, stg);
+    __syncthreads();
+
+    f32x16_s acc[4];
+    float tq[16];  // register copy of this lane's 16 row thresholds
+    auto load_tau = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
+    };
+    load_tau();
+    auto prefilter = [&]() -> unsigned {
+        unsigned pass = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float mx = fmaxf(fmaxf(acc[0][q], acc[1][q]), fmaxf(acc[2][q], acc[3][q]));
+            if (clamp) mx = fmaxf(mx, 0.f);
+            pass |= (mx > tq[q]) ? (1u << q) : 0u;
+        }
+        return pass;
+    };
+    auto offer = [&](int64_t col0, int group, unsigned pass) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (!((pass >> q) & 1u)) continue;
+            const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float t = tau[row];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lc = 32 * j + l31;
+                float v = acc[j][q];
+                if (clamp) v = (v > 0.f) ? v : 0.f;
+                const bool in_group = (group < 0) || ((lc >> 3) == group);
+                if (in_group && (col0 + lc < n) && v > t) {
+                    const int pos = atomicAdd(&cnt[row], 1);
+                    if (pos < SCAP) { pend_v[pos * SBM + row] = v; pend_i[pos * SBM + row] = (int)(col0 + lc); }
+                }
+            }
+        }
+    };
+    auto merge_wave = [&]() {
+        if (h == 0) {
+            const int row = 32 * wave + l31;
+            const int c = cnt[row] < SCAP ? cnt[row] : SCAP;
+            for (int p = 0; p < c; ++p) {
+                const float v = pend_v[p * SBM + row];
+                const int ix = pend_i[p * SBM + row];
+                int j = k - 1;
+                if (before_s(v, ix, list_v[j * SBM + row], list_i[j * SBM + row])) {
+                    while (j > 0 && before_s(v, ix, list_v[(j - 1) * SBM + row], list_i[(j - 1) * SBM + row])) {
+                        list_v[j * SBM + row] = list_v[(j - 1) * SBM + row];
+                        list_i[j * SBM + row] = list_i[(j - 1) * SBM + row];
+                        --j;
+                    }
+                    list_v[j * SBM + row] = v;
+                    list_i[j * SBM + row] = ix;
+                }
+            }
+            cnt[row] = 0;
+            if (row0 + row < m) tau[row] = list_v[(k - 1) * SBM + row];
+        }
+    };
+
+    int64_t g = 0;
+    int c_prev = 0;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c, ++g) {
+            g_load(g + 1, stg);
+            const char* bs = Bs + (int)(g & 1) * SSLOT + l31 * SROW + h * 16;
+            bf16x8_s bq[2][3];  // the three B planes of one (k-step, column block), one step ahead of their MFMAs
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {   // st = 4 ks + j
+                const int ks = st >> 2, j = st & 3;
+                if (st + 1 < 8) {
+                    const int ks1 = (st + 1) >> 2, j1 = (st + 1) & 3;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bq[(st + 1) & 1][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + 32 * j1 * SROW + ks1 * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8_s* b = bq[st & 1];
+                const int kk = 2 * c + ks;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[kk], b[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[kk], b[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[kk], b[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[0], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s_write_from((int)((g + 1) & 1), stg);   // its readers (chunk g - 1) all passed the previous barrier
+            __syncthreads();
+        }
+        const int64_t col0 = tile * SBN;
+        const unsigned pass = prefilter();
+        if (__any(pass != 0u)) {  // candidates are appended; lists and thresholds catch up when a buffer is half full
+            offer(col0, -1, pass);
+            const int my_row = 32 * wave + l31;
+            const int c_now = (h == 0) ? cnt[my_row] : 0;
+            if (__any(c_now > SCAP)) {  // overflow: keep the older appends, re-offer this tile in 16 groups of 8 columns
+                if (h == 0) cnt[my_row] = c_prev;
+                merge_wave();
+                for (int grp = 0; grp < SBN / 8; ++grp) {
+                    offer(col0, grp, pass);
+                    merge_wave();
+                }
+                c_prev = 0;
+                load_tau();
+            } else if (__any(c_now > SCAP / 2)) {
+                merge_wave();
+                c_prev = 0;
+                load_tau();
+            } else {
+                c_prev = c_now;
+            }
+        }
+    }
+    merge_wave();  // whatever is still pending
+    __syncthreads();
+    if (tid < SBM && row0 + tid < m) {
+        for (int j = 0; j < k; ++j) {
+            out_idx[(row0 + tid) * k + j] = list_i[j * SBM + tid];
+            if (out_val) out_val[(row0 + tid) * k + j] = list_v[j * SBM + tid];
+        }
+    }
+}
+
+static int64_t split_rows_pad(int64_t n) { return (n + SBN - 1) / SBN * SBN; }
+static int split_nch(int r) { return r <= 32 ? 1 : r <= 64 ? 2 : 4; }
+
+template <int NCH>
+static int launch_predict_topk_split(const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
+                                     int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
+    const size_t lds = (size_t)2 * SSLOT + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)SCAP * SBM + 8 * (size_t)k * SBM;
+    static LdsGrant grant;  // per template instance
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NCH>), lds, grant)) return rc;
+    const int64_t blocks = (m + SBM - 1) / SBM;
+    TMF_REQUIRE_LAUNCH(blocks, 512, "predict_topk_split");
+    hipLaunchKernelGGL((k_predict_topk_split<NCH>), dim3((unsigned)blocks), dim3(512), lds, stream, A, Bp, m, n, n_pad, K, lda, k,
+                       clamp, out_idx, out_val);
+    return check_launch("tmf_predict_topk_split_f32");
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_predict_topk_split_supported(int r, int k) {
+    return r >= 1 && r <= tmf::SMAXR && k >= 1 && k <= tmf::SMAXK;
+}
+
+extern "C" size_t tmf_predict_topk_split_workspace_bytes(int64_t n, int r) {
+    if (n <= 0 || r < 1 || r > tmf::SMAXR) return 0;
+    return (size_t)3 * (size_t)tmf::split_rows_pad(n) * (size_t)(32 * tmf::split_nch(r)) * sizeof(__bf16);
+}
+
+extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
+                                          int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (m == 0) return TMF_OK;
+    TMF_REQUIRE(A && B && out_idx && m > 0 && n > 0 && r > 0, "predict_topk_split: bad arguments");
+    TMF_REQUIRE(lda >= r && ldb >= r && (lda % 4 == 0) && ((uintptr_t)A % 16 == 0),
+                "predict_topk_split: the user table must be 16-byte aligned with ld %% 4 == 0");
+    TMF_REQUIRE(k >= 1 && k <= n, "predict_topk_split: k=%d must be in [1, n=%lld]", k, (long long)n);
+    TMF_REQUIRE(n < ((int64_t)1 << 31), "predict_topk_split: too many items");
+    if (!tmf_predict_topk_split_supported(r, k)) {
+        tmf::set_error("predict_topk_split: supports k <= %d and n_components <= %d (got k=%d, r=%d)", tmf::SMAXK, tmf::SMAXR, k, r);
+        return TMF_E_UNSUPPORTED;
+    }
+    const size_t need = tmf_predict_topk_split_workspace_bytes(n, r);
+    TMF_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
+                "predict_topk_split: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = tmf::split_nch(r), ldp = 32 * nch;
+    const int64_t n_pad = tmf::split_rows_pad(n);
+    __bf16* Bp = reinterpret_cast<__bf16*>(workspace);
+    {
+        const int64_t threads = n_pad * (ldp / 8), blocks = (threads + 255) / 256;
+        TMF_REQUIRE_LAUNCH(blocks, 256, "predict_topk_split (item planes)");
+        hipLaunchKernelGGL(tmf::k_split3_rows, dim3((unsigned)blocks), dim3(256), 0, s, B, n, r, ldb, Bp, n_pad, ldp);
+        if (int rc = tmf::check_launch("tmf_predict_topk_split_f32 (item planes)")) return rc;
+    }
+    if (nch == 1) return tmf::launch_predict_topk_split<1>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
+    if (nch == 2) return tmf::launch_predict_topk_split<2>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
+    return tmf::launch_predict_topk_split<4>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
+}
