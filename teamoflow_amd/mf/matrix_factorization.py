@@ -90,6 +90,7 @@ class MatrixFactorization:
         self.plan_seconds_ = 0.0  # extension: time spent building the index structures of the last fit
         self.verbose = True
         self.factor_dtype = torch.float32  # extension: torch.bfloat16 = bf16 factor storage, fp32 arithmetic
+        self.predict_arithmetic = None     # extension: 'fp32' | 'split' | 'auto' for the fused top-k of fp32 tables (_ops.predict_topk)
         self.data_parallel = False         # extension: split the users over torch.distributed ranks (teamoflow_amd/dist.py)
         # extension: q >= 1 = item-row-sharded V in q windows per rank (dist.fit_item_sharded): the item table is owned in
         # row blocks and streamed window by window instead of being replicated - for catalogs beyond one GPU's memory
@@ -359,7 +360,8 @@ class MatrixFactorization:
             scores = _ops.predict_gemm(self.user_embedding[users:users + 1], self.item_embedding)
             return _ops.topk_stable(scores, k, clamp_negatives=clamp)[0]
         if _ops.fused_topk_supported(self.user_embedding, self.item_embedding, k):
-            return _ops.predict_topk(self.user_embedding, self.item_embedding, k, clamp_negatives=clamp)
+            return _ops.predict_topk(self.user_embedding, self.item_embedding, k, clamp_negatives=clamp,
+                                     arithmetic=getattr(self, 'predict_arithmetic', None))
         out = []
         for b, e in self._user_blocks():
             scores = _ops.predict_gemm(self.user_embedding[b:e], self.item_embedding)

@@ -1,0 +1,150 @@
+"""tmf_predict_topk_split_f32 (fp32 factors on the bf16 matrix cores, three exact bf16 planes, six products): the same
+contract as the fp32 MFMA kernel - tf.math.top_k order (value desc, index asc), values fp32-accurate - checked against the
+CPU oracle (oracle/sparse_ref.topk_stable, oracle/dense_ref.tf_top_k) and an fp64 product.  Reference semantics:
+matrix_factorization.py:236-248 (recall_at_k) and :424-438 (retrieve_user_recs): tf.math.top_k(U V^T, k)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from teamoflow_amd import _lib, _ops
+    _lib.get()
+    return _ops
+
+
+def expected(sc, k, clamp):
+    from oracle import sparse_ref as S
+    return S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_exact_on_small_integer_factors(ops, seed):
+    """Small-integer factors: every plane product and every sum is exact, so the split kernel must return the oracle's
+    ranking bit for bit - with exact score ties across tiles, clamping, ragged last tiles, every table width class
+    (<= 32, <= 64, <= 128) and catalogs long enough for the warm-up pass (>= 256 tiles)."""
+    rng = np.random.default_rng(4100 + seed)
+    m = int(rng.integers(1, 600))
+    n = int(rng.choice([1, 7, 128, 129, 1000, 4097, 16384, 20011, 33000, 40000]))
+    r = int(rng.choice([1, 3, 8, 31, 32, 33, 50, 64, 65, 100, 127, 128]))
+    k = int(min(n, rng.choice([1, 2, 5, 10, 16, 17, 32])))
+    span = int(rng.choice([1, 2, 4]))
+    U = rng.integers(-span, span + 1, (m, r)).astype(np.float32)
+    V = rng.integers(-span, span + 1, (n, r)).astype(np.float32)
+    clamp = bool(rng.integers(0, 2))
+    sc = U @ V.T
+    vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic='split')
+    ref = expected(sc, k, clamp)
+    assert np.array_equal(got.cpu().numpy(), ref), (m, n, r, k, clamp)
+    assert np.array_equal(vals.cpu().numpy(), np.take_along_axis(np.where(sc > 0, sc, 0) if clamp else sc, ref, 1))
+
+
+@pytest.mark.parametrize('m,n,r,k,clamp', [(700, 3000, 128, 10, False), (300, 129, 5, 3, False), (256, 128, 32, 32, True),
+                                            (513, 5000, 64, 16, False), (300, 1000, 100, 10, True), (1024, 40000, 128, 10, False),
+                                            (640, 33001, 64, 5, False), (333, 70000, 24, 1, False)])
+def test_values_are_fp32_accurate(ops, m, n, r, k, clamp):
+    """Gaussian factors at the scale of normalised tables: values against an fp64 product (tolerance 1e-6 of the largest score -
+    the 1e-5 gate of the predictions with a decade to spare - and no worse than twice the fp32 MFMA kernel's own error), the
+    ranking against the oracle's top_k of the fp64 scores wherever the k-th and (k+1)-th scores are further apart than that."""
+    from oracle import dense_ref as D
+    g = torch.Generator().manual_seed(m * 31 + n)
+    U = (torch.randn(m, r, generator=g) * 0.05).float()
+    V = (torch.randn(n, r, generator=g) * 0.05).float()
+    ref = U.double() @ V.double().T
+    if clamp:
+        ref = ref.clamp_min(0)
+    norm = float(ref.abs().max())
+    v32, i32 = ops.predict_topk(U, V, k, clamp_negatives=clamp, return_values=True, arithmetic='fp32')
+    vs, ix = ops.predict_topk(U, V, k, clamp_negatives=clamp, return_values=True, arithmetic='split')
+    vs, ix, v32, i32 = vs.cpu(), ix.cpu().long(), v32.cpu(), i32.cpu().long()
+    e32 = float((v32.double() - torch.gather(ref, 1, i32)).abs().max()) / norm
+    es = float((vs.double() - torch.gather(ref, 1, ix)).abs().max()) / norm
+    assert es < 1e-6 and es <= 2 * e32 + 1e-7, (es, e32)
+    if k > 1:   # sorted under the total order
+        assert bool(((vs[:, :-1] > vs[:, 1:]) | ((vs[:, :-1] == vs[:, 1:]) & (ix[:, :-1] < ix[:, 1:]))).all())
+    kk = min(k + 1, n)
+    wv, wi = D.tf_top_k(ref, kk)
+    gaps = (wv[:, :-1] - wv[:, 1:]) if kk > k else (wv[:, :-1] - wv[:, 1:])
+    clear = (gaps.min(1).values > 4e-6 * norm) if gaps.numel() else torch.ones(m, dtype=torch.bool)
+    assert clear.float().mean() > 0.5 or clamp
+    assert torch.equal(ix[clear], wi[clear, :k])
+
+
+def test_split_is_exact_per_value(ops):
+    """One user per value x, one item [1.0]: the score is x3 + x2 + x1 summed in fp32 and must give x back exactly - the three
+    planes lose nothing, for values across the exponent range, values that round up to the next binade in bf16, and a value
+    that would round to inf in bf16 (truncated instead)."""
+    xs = np.array([0.0, 1.0, -1.0, 1.0 + 2 ** -23, 1.0 - 2 ** -24, 0.1, -0.3333333, 3.14159274, 255.99998, 1e-20, -7.7e-12, 6.5e4 + 1,
+                   1.9999999, 3.3e38, -3.3e38, 1e-30, 123456.789, 2 ** -100 * 1.2345678], dtype=np.float32)
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([xs, (rng.standard_normal(4000) * np.exp(rng.uniform(-30, 30, 4000))).astype(np.float32)])
+    U = torch.tensor(xs[:, None].copy())
+    vals, idx = ops.predict_topk(U, torch.ones(1, 1), 1, return_values=True, arithmetic='split')
+    assert np.array_equal(vals.cpu().numpy()[:, 0], xs) and int(idx.abs().max()) == 0
+
+
+def test_deferred_merges_and_overflow(ops):
+    """Records every 20..41 items (pending buffers fill over several tiles, rows merge at different times, the last records sit
+    in the last tiles), and scores increasing with the item index (every tile overflows the pending buffer)."""
+    n, r, m = 3001, 8, 300
+    period = 20 + 3 * np.arange(r)
+    j = np.arange(n)
+    V = np.where(j[:, None] % period[None, :] == 0, (j // 16 + 1)[:, None], -1).astype(np.float32)
+    U = np.eye(r, dtype=np.float32)[np.arange(m) % r]
+    U[7] = 0
+    sc = U @ V.T
+    for k in (1, 10, 32):
+        for clamp in (False, True):
+            vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic='split')
+            ref = expected(sc, k, clamp)
+            assert np.array_equal(got.cpu().numpy(), ref), (k, clamp)
+    inc = torch.arange(40000, dtype=torch.float32)[:, None] * torch.ones(1, 4)      # long enough for the warm-up pass
+    got = ops.predict_topk(torch.ones(7, 4), inc, 5, arithmetic='split').cpu().tolist()
+    assert got == [[39999, 39998, 39997, 39996, 39995]] * 7
+    Z = torch.zeros(200, 16)                                                         # everything clamped to 0: 0..k-1
+    assert ops.predict_topk(Z, torch.ones(40000, 16), 10, clamp_negatives=True, arithmetic='split').cpu().tolist() == [list(range(10))] * 200
+    dec = -inc                                                                       # best items first: the warm-up bound is tight
+    assert ops.predict_topk(torch.ones(3, 4), dec, 4, arithmetic='split').cpu().tolist() == [[0, 1, 2, 3]] * 3
+
+
+def test_limits_and_errors(ops):
+    from teamoflow_amd import _lib
+    lib = _lib.get()
+    assert lib.tmf_predict_topk_split_supported(128, 32) == 1 and lib.tmf_predict_topk_split_supported(129, 10) == 0
+    assert lib.tmf_predict_topk_split_supported(64, 33) == 0 and lib.tmf_predict_topk_split_workspace_bytes(1000, 129) == 0
+    assert lib.tmf_predict_topk_split_workspace_bytes(1000, 100) == 3 * 1024 * 128 * 2
+    with pytest.raises(ValueError):
+        ops.predict_topk(torch.ones(4, 200), torch.ones(9, 200), 2, arithmetic='split')
+    with pytest.raises(ValueError):
+        ops.predict_topk(torch.ones(4, 8), torch.ones(99, 8), 40, arithmetic='split')
+    x = torch.ones(8, 8, device='cuda')
+    out = torch.empty(8, 2, dtype=torch.int32, device='cuda')
+    ws = torch.empty(64, dtype=torch.uint8, device='cuda')
+    rc = lib.tmf_predict_topk_split_f32(_lib.ptr(x), _lib.ptr(x), 8, 8, 8, 8, 8, 2, 0, _lib.ptr(out), None, _lib.ptr(ws), 64,
+                                        _lib.stream_ptr())
+    assert rc != 0 and b'workspace' in lib.tmf_last_error()
+    big = torch.ones(4, 132, device='cuda')
+    rc = lib.tmf_predict_topk_split_f32(_lib.ptr(big), _lib.ptr(big), 4, 4, 130, 132, 132, 2, 0, _lib.ptr(out), None, _lib.ptr(ws), 64,
+                                        _lib.stream_ptr())
+    assert rc != 0 and b'supports' in lib.tmf_last_error()
+    assert lib.tmf_predict_topk_split_f32(None, None, 0, 5, 4, 4, 4, 1, 0, None, None, None, ctypes.c_size_t(0), _lib.stream_ptr()) == 0
+
+
+def test_model_level_switch(ops):
+    """retrieve_user_recs / recall_at_k through the class surface with the split arithmetic selected: same lists as the fp32 kernel
+    on a trained-table-like input (matrix_factorization.py:424-438)."""
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    g = torch.Generator().manual_seed(5)
+    U, V = torch.randn(500, 64, generator=g) * 0.1, torch.randn(20000, 64, generator=g) * 0.1
+    model = MatrixFactorization(64)
+    model.user_embedding, model.item_embedding = U.cuda(), V.cuda()
+    model.predict_arithmetic = 'fp32'
+    a = model.retrieve_user_recs(k=10)
+    model.predict_arithmetic = 'split'
+    b = model.retrieve_user_recs(k=10)
+    assert a.dtype == np.int32 and (a == b).all(1).mean() > 0.999

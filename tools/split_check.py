@@ -8,7 +8,8 @@ dev = 'cuda'
 torch.manual_seed(0)
 ok = True
 for (m, n, r, k, clamp) in ((1000, 3000, 128, 10, False), (513, 129, 5, 3, False), (256, 128, 32, 32, True), (700, 5000, 64, 16, False),
-                            (300, 1000, 100, 10, False), (4096, 20000, 128, 10, False), (64, 1, 7, 1, False)):
+                            (300, 1000, 100, 10, False), (4096, 20000, 128, 10, False), (64, 1, 7, 1, False), (2048, 40000, 128, 10, False),
+                            (1500, 50001, 64, 16, True), (1024, 33000, 32, 5, False), (600, 70000, 96, 1, False)):
     U = torch.randn(m, r, device=dev) * 0.05
     V = torch.randn(n, r, device=dev) * 0.05
     ref = U.double() @ V.double().T
