@@ -12,7 +12,7 @@
 // Structure: that of k_predict_topk_bf16 (tmf_predict.hip).  512 threads = 8 waves own 256 users, 32 per wave; the users'
 // rows are split in registers at load time and stay there as A fragments of the three planes (3 x K/16 x 4 VGPRs per lane).
 // The item table is split once per call into a caller-provided workspace ([3][n_pad][32 NCH] bf16, zero padded), and item
-// tiles of 128 stream through a 2-slot LDS ring in k-chunks of 32: [plane][item][64 B of data + 16 B pad] - an 80-byte row
+// tiles of 128 (64 at r > 64) stream through a 2-slot LDS ring in k-chunks of 32 (64): [plane][item][64 B of data + 16 B pad] - an 80-byte row
 // pitch puts 16 consecutive rows on 16 different 16-byte bank slots (5 i mod 16), so the ds_read_b128 operand reads are
 // conflict-free.  Per (k-step, 32-column block) a wave reads three B fragments and issues six MFMAs: half an LDS read per
 // MFMA, where the one-plane bf16 kernel needs one.  Candidates reach the rows' sorted lists as in the bf16 kernel
@@ -29,8 +29,8 @@ typedef float f32x16_s __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
 
-constexpr int SBM = 256, SBN = 128, SROW = 80 /* bytes */, SCAP = 16, SMAXK = 32, SMAXR = 128;
-constexpr int SPLANE = SBN * SROW, SSLOT = 3 * SPLANE;
+constexpr int SBM = 256, SCAP = 16, SMAXK = 32, SMAXR = 128;
+constexpr int kSplitRowsPad = 128;   // the item planes are padded to a multiple of this many rows (a multiple of every tile width)
 
 __device__ __forceinline__ bool before_s(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
@@ -44,6 +44,21 @@ __device__ __forceinline__ void split3(float x, __bf16& x1, __bf16& x2, __bf16& 
     const float r1 = x - (float)h;
     x2 = (__bf16)r1;
     x3 = (__bf16)(r1 - (float)x2);
+}
+
+// The k-th largest of the 32 values a half-wave holds (one per lane), returned to every lane of the half.
+__device__ __forceinline__ float half_kth_largest(float x, int k, int l31, int h) {
+    float res = -INFINITY;
+    for (int i = 0; i < k; ++i) {
+        float mx = x;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        res = mx;
+        const uint64_t b = __ballot(x == mx);
+        const uint32_t mine = h ? (uint32_t)(b >> 32) : (uint32_t)b;
+        if (mine != 0u && l31 == __ffs(mine) - 1) x = -INFINITY;   // one holder of the maximum leaves
+    }
+    return res;
 }
 
 // Rows [0, rows_pad) x columns [0, ldp) of the three planes; everything outside [0, rows) x [0, r) is zero.
@@ -68,12 +83,17 @@ __global__ __launch_bounds__(256) void k_split3_rows(const float* __restrict__ X
     *reinterpret_cast<bf16x8_s*>(out + 2 * plane + o) = p3;
 }
 
-template <int NCH>  // K_PAD = 32 * NCH
+// NJ column blocks of 32 items per tile, KS k-steps of 16 per chunk, NCH chunks per tile: K_PAD = 16 KS NCH.
+// (NJ, KS) = (4, 2): 128-item tiles, 64 accumulator registers - narrow tables, where the A fragments are few;
+//            (2, 4):  64-item tiles, 32 accumulator registers - leaves room for the 96 A registers of r = 128 without spills.
+// Either way a chunk is 512 16-byte pieces per plane (one per thread) and 48 MFMAs per wave between two barriers.
+template <int NJ, int KS, int NCH>
 __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __restrict__ A, const __bf16* __restrict__ Bp,
                                                                int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda, int k,
                                                                int clamp, int32_t* __restrict__ out_idx,
                                                                float* __restrict__ out_val) {
-    constexpr int LDP = 32 * NCH;
+    constexpr int LDP = 16 * KS * NCH, SBN = 32 * NJ, SROW = 32 * KS + 16 /* bytes: pad 16 */, SPLANE = SBN * SROW, SSLOT = 3 * SPLANE;
+    constexpr int NK = KS * NCH;   // k-steps per plane
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* Bs = smem_raw;                                               // [2 slots][3 planes][SBN][SROW] bytes
     float* tau = reinterpret_cast<float*>(Bs + 2 * SSLOT);             // [SBM]
@@ -88,12 +108,12 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
     const int64_t row0 = (int64_t)blockIdx.x * SBM;
 
     // A fragments of the three planes: a?[kk] = plane?(U[row0 + 32 wave + l31][16 kk + 8 h .. + 8))
-    bf16x8_s a1[2 * NCH], a2[2 * NCH], a3[2 * NCH];
+    bf16x8_s a1[NK], a2[NK], a3[NK];
     {
         const int64_t r = row0 + 32 * wave + l31;
         const float* p = A + (r < m ? r : 0) * lda;
 #pragma unroll
-        for (int kk = 0; kk < 2 * NCH; ++kk) {
+        for (int kk = 0; kk < NK; ++kk) {
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = 0.f;
@@ -121,16 +141,24 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
         for (int j = 0; j < k; ++j) { list_v[j * SBM + t] = -INFINITY; list_i[j * SBM + t] = 0x7fffffff; }
     }
 
-    // staging: thread -> (item tid / 4, 16-byte piece tid % 4 of the 64-byte k-chunk) of each plane
-    const int s_item = tid >> 2, s_slot = tid & 3;
+    // staging: thread -> (item tid / (2 KS), 16-byte piece tid % (2 KS) of the 32 KS-byte k-chunk) of each plane
+    const int s_item = tid / (2 * KS), s_slot = tid % (2 * KS);
     const int64_t ntiles = (n + SBN - 1) / SBN;
     const int64_t nchunks = ntiles * NCH;
+    // Warm-up: the first `warm` tiles are multiplied twice.  The first time only a running maximum per (row, lane) is kept -
+    // 32 maxima of disjoint item groups per row, so their k-th largest is the score of a k-th distinct item and a valid lower
+    // bound of the row's final k-th value.  The scan then restarts at tile 0 with every threshold just below that bound:
+    // the rows skip the phase in which nearly every score is a candidate (half of all k (1 + ln(n / k)) insertions of a row
+    // fall into its first ~5 tiles) for warm / ntiles (<= 1/64) more MFMA work.
+    const int64_t warm = (k <= 16 && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
+    const int64_t warm_chunks = warm * NCH;
     const int64_t plane = n_pad * LDP;
     const __bf16* src0 = Bp + (int64_t)s_item * LDP + 8 * s_slot;
     bf16x8_s stg[3];     // chunk g + 1 on its way to LDS while chunk g is multiplied (48 MFMAs per wave: ~3000 cycles per chunk)
     auto g_load = [&](int64_t g, bf16x8_s* stage) {
-        const int64_t gg = g < nchunks ? g : nchunks - 1;   // read-ahead past the last chunk re-reads it (never written to LDS use)
-        const __bf16* s = src0 + (gg / NCH) * (int64_t)SBN * LDP + 32 * (int)(gg % NCH);
+        int64_t gg = g < warm_chunks ? g : g - warm_chunks;
+        gg = gg < nchunks ? gg : nchunks - 1;   // the read-ahead past the last chunk re-reads it
+        const __bf16* s = src0 + (gg / NCH) * (int64_t)SBN * LDP + 16 * KS * (int)(gg % NCH);
 #pragma unroll
         for (int p = 0; p < 3; ++p) stage[p] = *reinterpret_cast<const bf16x8_s*>(s + p * plane);
     };
@@ -142,38 +170,46 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
     g_load(0, stg); s_write_from(0, stg);
     __syncthreads();
 
-    f32x16_s acc[4];
+    f32x16_s acc[NJ];
     float tq[16];  // register copy of this lane's 16 row thresholds
     auto load_tau = [&]() {
 #pragma unroll
         for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
     };
-    load_tau();
+    if (warm > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tq[q] = -INFINITY;   // running maxima during the warm-up
+    } else {
+        load_tau();
+    }
     auto prefilter = [&]() -> unsigned {
         unsigned pass = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            float mx = fmaxf(fmaxf(acc[0][q], acc[1][q]), fmaxf(acc[2][q], acc[3][q]));
+            float mx = acc[0][q];
+#pragma unroll
+            for (int j = 1; j < NJ; ++j) mx = fmaxf(mx, acc[j][q]);
             if (clamp) mx = fmaxf(mx, 0.f);
             pass |= (mx > tq[q]) ? (1u << q) : 0u;
         }
         return pass;
     };
-    auto offer = [&](int64_t col0, int group, unsigned pass) {
+    const int n32 = (int)n;
+    auto offer = [&](int col0, int group, unsigned pass) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (!((pass >> q) & 1u)) continue;
             const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
             const float t = tau[row];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int lc = 32 * j + l31;
                 float v = acc[j][q];
                 if (clamp) v = (v > 0.f) ? v : 0.f;
                 const bool in_group = (group < 0) || ((lc >> 3) == group);
-                if (in_group && (col0 + lc < n) && v > t) {
+                if (in_group && (col0 + lc < n32) && v > t) {
                     const int pos = atomicAdd(&cnt[row], 1);
-                    if (pos < SCAP) { pend_v[pos * SBM + row] = v; pend_i[pos * SBM + row] = (int)(col0 + lc); }
+                    if (pos < SCAP) { pend_v[pos * SBM + row] = v; pend_i[pos * SBM + row] = col0 + lc; }
                 }
             }
         }
@@ -197,15 +233,26 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
                 }
             }
             cnt[row] = 0;
-            if (row0 + row < m) tau[row] = list_v[(k - 1) * SBM + row];
+            if (row0 + row < m) tau[row] = fmaxf(tau[row], list_v[(k - 1) * SBM + row]);   // never below the warm-up bound
         }
     };
 
     int64_t g = 0;
     int c_prev = 0;
-    for (int64_t tile = 0; tile < ntiles; ++tile) {
+    for (int64_t vt = 0; vt < warm + ntiles; ++vt) {
+        const int64_t tile = vt < warm ? vt : vt - warm;
+        if (warm > 0 && vt == warm) {   // thresholds from the warm-up maxima; the scan restarts at tile 0
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int q = 0; q < 16; ++q) {
+                const float t0 = half_kth_largest(tq[q], k, l31, h);
+                const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (l31 == 0 && row0 + row < m) tau[row] = t0 - fabsf(t0) * 1e-6f - 1e-30f;   // strictly below the bound
+            }
+            wave_lds_sync();
+            load_tau();
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 #pragma unroll
@@ -216,17 +263,17 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
 #pragma unroll
             for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE);
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {   // st = 4 ks + j
-                const int ks = st >> 2, j = st & 3;
-                if (st + 1 < 8) {
-                    const int ks1 = (st + 1) >> 2, j1 = (st + 1) & 3;
+            for (int st = 0; st < KS * NJ; ++st) {   // st = NJ ks + j
+                const int ks = st / NJ, j = st % NJ;
+                if (st + 1 < KS * NJ) {
+                    const int ks1 = (st + 1) / NJ, j1 = (st + 1) % NJ;
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
                         bq[(st + 1) & 1][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + 32 * j1 * SROW + ks1 * 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const bf16x8_s* b = bq[st & 1];
-                const int kk = 2 * c + ks;
+                const int kk = KS * c + ks;
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[kk], b[0], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[2], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[kk], b[1], acc[j], 0, 0, 0);
@@ -238,9 +285,25 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
             s_write_from((int)((g + 1) & 1), stg);   // its readers (chunk g - 1) all passed the previous barrier
             __syncthreads();
         }
-        const int64_t col0 = tile * SBN;
+        if (vt < warm) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float mx = acc[0][q];
+#pragma unroll
+                for (int j = 1; j < NJ; ++j) mx = fmaxf(mx, acc[j][q]);
+                if (clamp) mx = fmaxf(mx, 0.f);
+                tq[q] = fmaxf(tq[q], mx);
+            }
+            continue;
+        }
+        const int col0 = (int)(tile * SBN);
         const unsigned pass = prefilter();
-        if (__any(pass != 0u)) {  // candidates are appended; lists and thresholds catch up when a buffer is half full
+#ifdef TMF_SPLIT_NOCAND
+        if (k < 0 && __any(pass != 0u))
+#else
+        if (__any(pass != 0u))
+#endif
+        {  // candidates are appended; lists and thresholds catch up when a buffer is half full
             offer(col0, -1, pass);
             const int my_row = 32 * wave + l31;
             const int c_now = (h == 0) ? cnt[my_row] : 0;
@@ -272,18 +335,18 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
     }
 }
 
-static int64_t split_rows_pad(int64_t n) { return (n + SBN - 1) / SBN * SBN; }
-static int split_nch(int r) { return r <= 32 ? 1 : r <= 64 ? 2 : 4; }
+static int64_t split_rows_pad(int64_t n) { return (n + kSplitRowsPad - 1) / kSplitRowsPad * kSplitRowsPad; }
+static int split_ldp(int r) { return r <= 32 ? 32 : r <= 64 ? 64 : 128; }
 
-template <int NCH>
+template <int NJ, int KS, int NCH>
 static int launch_predict_topk_split(const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
                                      int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
-    const size_t lds = (size_t)2 * SSLOT + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)SCAP * SBM + 8 * (size_t)k * SBM;
+    const size_t lds = (size_t)2 * 3 * (32 * NJ) * (32 * KS + 16) + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)SCAP * SBM + 8 * (size_t)k * SBM;
     static LdsGrant grant;  // per template instance
-    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NCH>), lds, grant)) return rc;
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NJ, KS, NCH>), lds, grant)) return rc;
     const int64_t blocks = (m + SBM - 1) / SBM;
     TMF_REQUIRE_LAUNCH(blocks, 512, "predict_topk_split");
-    hipLaunchKernelGGL((k_predict_topk_split<NCH>), dim3((unsigned)blocks), dim3(512), lds, stream, A, Bp, m, n, n_pad, K, lda, k,
+    hipLaunchKernelGGL((k_predict_topk_split<NJ, KS, NCH>), dim3((unsigned)blocks), dim3(512), lds, stream, A, Bp, m, n, n_pad, K, lda, k,
                        clamp, out_idx, out_val);
     return check_launch("tmf_predict_topk_split_f32");
 }
@@ -296,7 +359,7 @@ extern "C" int tmf_predict_topk_split_supported(int r, int k) {
 
 extern "C" size_t tmf_predict_topk_split_workspace_bytes(int64_t n, int r) {
     if (n <= 0 || r < 1 || r > tmf::SMAXR) return 0;
-    return (size_t)3 * (size_t)tmf::split_rows_pad(n) * (size_t)(32 * tmf::split_nch(r)) * sizeof(__bf16);
+    return (size_t)3 * (size_t)tmf::split_rows_pad(n) * (size_t)tmf::split_ldp(r) * sizeof(__bf16);
 }
 
 extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
@@ -316,7 +379,7 @@ extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_
     TMF_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
                 "predict_topk_split: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
-    const int nch = tmf::split_nch(r), ldp = 32 * nch;
+    const int ldp = tmf::split_ldp(r);
     const int64_t n_pad = tmf::split_rows_pad(n);
     __bf16* Bp = reinterpret_cast<__bf16*>(workspace);
     {
@@ -325,7 +388,7 @@ extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_
         hipLaunchKernelGGL(tmf::k_split3_rows, dim3((unsigned)blocks), dim3(256), 0, s, B, n, r, ldb, Bp, n_pad, ldp);
         if (int rc = tmf::check_launch("tmf_predict_topk_split_f32 (item planes)")) return rc;
     }
-    if (nch == 1) return tmf::launch_predict_topk_split<1>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
-    if (nch == 2) return tmf::launch_predict_topk_split<2>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
-    return tmf::launch_predict_topk_split<4>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
+    if (ldp == 32) return tmf::launch_predict_topk_split<4, 2, 1>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
+    if (ldp == 64) return tmf::launch_predict_topk_split<4, 2, 2>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
+    return tmf::launch_predict_topk_split<2, 4, 2>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
 }
