@@ -28,8 +28,11 @@ namespace tmf {
 typedef float f32x16_s __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_s;
+typedef __attribute__((address_space(1))) const void gbl_void_s;
 
-constexpr int SBM = 256, SCAP = 16, SMAXK = 32, SMAXR = 128;
+constexpr int SBM = 256, SMAXK = 32, SMAXR = 128, SRING = 3;
+__host__ __device__ constexpr int split_cap(int k) { return k <= 16 ? 16 : 8; }   // pending entries per row: what the LDS leaves next to the lists
 constexpr int kSplitRowsPad = 128;   // the item planes are padded to a multiple of this many rows (a multiple of every tile width)
 
 __device__ __forceinline__ bool before_s(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -92,11 +95,12 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
                                                                int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda, int k,
                                                                int clamp, int32_t* __restrict__ out_idx,
                                                                float* __restrict__ out_val) {
-    constexpr int LDP = 16 * KS * NCH, SBN = 32 * NJ, SROW = 32 * KS + 16 /* bytes: pad 16 */, SPLANE = SBN * SROW, SSLOT = 3 * SPLANE;
+    constexpr int LDP = 16 * KS * NCH, SBN = 32 * NJ, SROW = 32 * KS /* bytes, unpadded: the image is written by LDS-DMA */, SPLANE = SBN * SROW, SSLOT = 3 * SPLANE;
     constexpr int NK = KS * NCH;   // k-steps per plane
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    char* Bs = smem_raw;                                               // [2 slots][3 planes][SBN][SROW] bytes
-    float* tau = reinterpret_cast<float*>(Bs + 2 * SSLOT);             // [SBM]
+    char* Bs = smem_raw;                                               // [SRING slots][3 planes][SBN][SROW] bytes
+    float* tau = reinterpret_cast<float*>(Bs + SRING * SSLOT);         // [SBM]
+    const int SCAP = split_cap(k);
     int* cnt = reinterpret_cast<int*>(tau + SBM);                      // [SBM]
     float* pend_v = reinterpret_cast<float*>(cnt + SBM);               // [SCAP][SBM]
     int* pend_i = reinterpret_cast<int*>(pend_v + SCAP * SBM);
@@ -141,40 +145,61 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
         for (int j = 0; j < k; ++j) { list_v[j * SBM + t] = -INFINITY; list_i[j * SBM + t] = 0x7fffffff; }
     }
 
-    // staging: thread -> (item tid / (2 KS), 16-byte piece tid % (2 KS) of the 32 KS-byte k-chunk) of each plane
-    const int s_item = tid / (2 * KS), s_slot = tid % (2 * KS);
-    const int64_t ntiles = (n + SBN - 1) / SBN;
-    const int64_t nchunks = ntiles * NCH;
+    // Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, two chunks in flight): one wave-instruction writes
+    // 1 KB of LDS lane by lane, so wave w fills rows [RW w, RW (w + 1)) of each plane - RW = 64 / SR rows of SR = 2 KS
+    // 16-byte pieces, unpadded.  Bank conflicts are avoided by a swizzle on the SOURCE side: LDS piece q of row i holds the
+    // row's piece q ^ swz(i), swz(i) = (i / (16 / SR)) % SR, which spreads the pieces that 16 consecutive rows read together
+    // over all 16 bank slots; the operand reads apply the same XOR.
+    constexpr int SR = 2 * KS, RW = 64 / SR;
+    static_assert(8 * RW == SBN, "eight waves fill one plane of a tile");
+    const int s_row = RW * wave + lane / SR;
+    const int s_piece = (lane % SR) ^ ((s_row / (16 / SR)) % SR);
+    const int ntiles = (int)((n + SBN - 1) / SBN);
+    const int nchunks = ntiles * NCH;
     // Warm-up: the first `warm` tiles are multiplied twice.  The first time only a running maximum per (row, lane) is kept -
     // 32 maxima of disjoint item groups per row, so their k-th largest is the score of a k-th distinct item and a valid lower
     // bound of the row's final k-th value.  The scan then restarts at tile 0 with every threshold just below that bound:
     // the rows skip the phase in which nearly every score is a candidate (half of all k (1 + ln(n / k)) insertions of a row
     // fall into its first ~5 tiles) for warm / ntiles (<= 1/64) more MFMA work.
-    const int64_t warm = (k <= 16 && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
-    const int64_t warm_chunks = warm * NCH;
+    const int warm = (k <= 16 && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
+    const int warm_chunks = warm * NCH;
     const int64_t plane = n_pad * LDP;
-    const __bf16* src0 = Bp + (int64_t)s_item * LDP + 8 * s_slot;
-    bf16x8_s stg[3];     // chunk g + 1 on its way to LDS while chunk g is multiplied (48 MFMAs per wave: ~3000 cycles per chunk)
-    auto g_load = [&](int64_t g, bf16x8_s* stage) {
-        int64_t gg = g < warm_chunks ? g : g - warm_chunks;
+    const __bf16* src0 = Bp + (int64_t)s_row * LDP + 8 * s_piece;
+    auto g_issue = [&](int g, int slot) {   // chunk g -> ring slot `slot` (three LDS-DMA loads per wave)
+        int gg = g < warm_chunks ? g : g - warm_chunks;
         gg = gg < nchunks ? gg : nchunks - 1;   // the read-ahead past the last chunk re-reads it
-        const __bf16* s = src0 + (gg / NCH) * (int64_t)SBN * LDP + 16 * KS * (int)(gg % NCH);
+        const __bf16* s = src0 + (int64_t)(gg / NCH) * (SBN * LDP) + 16 * KS * (gg % NCH);
+        char* dst = Bs + slot * SSLOT + wave * 1024;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) stage[p] = *reinterpret_cast<const bf16x8_s*>(s + p * plane);
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void_s*)(s + p * plane), (lds_void_s*)(dst + p * SPLANE), 16, 0, 0);
     };
-    auto s_write_from = [&](int slot, const bf16x8_s* src) {
-        char* dst = Bs + slot * SSLOT + s_item * SROW + s_slot * 16;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8_s*>(dst + p * SPLANE) = src[p];
+    // Chunk g + 2 is issued at the top of iteration g into the slot read in iteration g - 1 (every wave passed the barrier
+    // that ended it).  At the bottom a counted wait leaves only those three loads in flight - chunk g + 1 has landed - and
+    // the raw barrier publishes it to the readers of iteration g + 1 (a __syncthreads() would drain the DMA queue).
+    auto ring_step = [&]() {
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
-    g_load(0, stg); s_write_from(0, stg);
-    __syncthreads();
+    __syncthreads();   // lists and thresholds initialised; no DMA in flight yet
+    g_issue(0, 0);
+    g_issue(1, 1);
+    ring_step();
+    const int rd_swz = (l31 / (16 / SR)) % SR;   // swz(32 j + l31) for every column block j
 
     f32x16_s acc[NJ];
     float tq[16];  // register copy of this lane's 16 row thresholds
+    // accumulator register q of this lane belongs to row rbase + qoff(q) of the workgroup: per-lane base pointers + constants,
+    // so that every per-row LDS access is one base register and an immediate offset (16 address registers per array otherwise)
+    const int rbase = 32 * wave + 4 * h;
+    auto qoff = [](int q) { return (q & 3) + 8 * (q >> 2); };
+    float* const tau_l = tau + rbase;
+    int* const cnt_l = cnt + rbase;
+    float* const pend_v_l = pend_v + rbase;
+    int* const pend_i_l = pend_i + rbase;
     auto load_tau = [&]() {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
+        for (int q = 0; q < 16; ++q) tq[q] = tau_l[qoff(q)];
     };
     if (warm > 0) {
 #pragma unroll
@@ -195,23 +220,30 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
         return pass;
     };
     const int n32 = (int)n;
+    // Appending candidates takes no LDS atomic (hipcc drains the LDS-DMA queue, vmcnt(0), before every LDS atomic): the lanes
+    // of a half-wave that hold candidates of one row take consecutive slots by ballot + popcount behind the row's count, which
+    // they read once per row and write back (all the same value) at the end.  Rows are private to a wave.
+    const uint32_t lt_mask = (1u << l31) - 1u;
     auto offer = [&](int col0, int group, unsigned pass) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (!((pass >> q) & 1u)) continue;
-            const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
-            const float t = tau[row];
+            const float t = tau_l[qoff(q)];
+            int c0 = cnt_l[qoff(q)];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int lc = 32 * j + l31;
                 float v = acc[j][q];
                 if (clamp) v = (v > 0.f) ? v : 0.f;
                 const bool in_group = (group < 0) || ((lc >> 3) == group);
-                if (in_group && (col0 + lc < n32) && v > t) {
-                    const int pos = atomicAdd(&cnt[row], 1);
-                    if (pos < SCAP) { pend_v[pos * SBM + row] = v; pend_i[pos * SBM + row] = col0 + lc; }
-                }
+                const bool cand = in_group && (col0 + lc < n32) && v > t;
+                const uint64_t b = __ballot(cand);
+                const uint32_t mh = h ? (uint32_t)(b >> 32) : (uint32_t)b;
+                const int pos = c0 + __popc(mh & lt_mask);
+                if (cand && pos < SCAP) { pend_v_l[pos * SBM + qoff(q)] = v; pend_i_l[pos * SBM + qoff(q)] = col0 + lc; }
+                c0 += __popc(mh);
             }
+            cnt_l[qoff(q)] = c0;
         }
     };
     auto merge_wave = [&]() {
@@ -237,16 +269,15 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
         }
     };
 
-    int64_t g = 0;
+    int g = 0, slot = 0;   // chunk counter and its ring slot (g % SRING)
     int c_prev = 0;
-    for (int64_t vt = 0; vt < warm + ntiles; ++vt) {
-        const int64_t tile = vt < warm ? vt : vt - warm;
+    for (int vt = 0; vt < warm + ntiles; ++vt) {
+        const int tile = vt < warm ? vt : vt - warm;
         if (warm > 0 && vt == warm) {   // thresholds from the warm-up maxima; the scan restarts at tile 0
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const float t0 = half_kth_largest(tq[q], k, l31, h);
-                const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (l31 == 0 && row0 + row < m) tau[row] = t0 - fabsf(t0) * 1e-6f - 1e-30f;   // strictly below the bound
+                if (l31 == 0 && row0 + rbase + qoff(q) < m) tau_l[qoff(q)] = t0 - fabsf(t0) * 1e-6f - 1e-30f;   // strictly below the bound
             }
             wave_lds_sync();
             load_tau();
@@ -257,11 +288,14 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c, ++g) {
-            g_load(g + 1, stg);
-            const char* bs = Bs + (int)(g & 1) * SSLOT + l31 * SROW + h * 16;
+            g_issue(g + 2, slot == 0 ? 2 : slot - 1);
+            const char* bs = Bs + slot * SSLOT + l31 * SROW;
+            int po[KS];   // byte offset of this lane's piece of k-step ks inside its row
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) po[ks] = 16 * ((2 * ks + h) ^ rd_swz);
             bf16x8_s bq[2][3];  // the three B planes of one (k-step, column block), one step ahead of their MFMAs
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE);
+            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + po[0]);
 #pragma unroll
             for (int st = 0; st < KS * NJ; ++st) {   // st = NJ ks + j
                 const int ks = st / NJ, j = st % NJ;
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
                     const int ks1 = (st + 1) / NJ, j1 = (st + 1) % NJ;
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        bq[(st + 1) & 1][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + 32 * j1 * SROW + ks1 * 32);
+                        bq[(st + 1) & 1][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + 32 * j1 * SROW + po[ks1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const bf16x8_s* b = bq[st & 1];
@@ -282,8 +316,8 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[0], acc[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            s_write_from((int)((g + 1) & 1), stg);   // its readers (chunk g - 1) all passed the previous barrier
-            __syncthreads();
+            ring_step();
+            slot = (slot == SRING - 1) ? 0 : slot + 1;
         }
         if (vt < warm) {
 #pragma unroll
@@ -296,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
             }
             continue;
         }
-        const int col0 = (int)(tile * SBN);
+        const int col0 = tile * SBN;
         const unsigned pass = prefilter();
 #ifdef TMF_SPLIT_NOCAND
         if (k < 0 && __any(pass != 0u))
@@ -341,7 +375,7 @@ static int split_ldp(int r) { return r <= 32 ? 32 : r <= 64 ? 64 : 128; }
 template <int NJ, int KS, int NCH>
 static int launch_predict_topk_split(const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
                                      int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
-    const size_t lds = (size_t)2 * 3 * (32 * NJ) * (32 * KS + 16) + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)SCAP * SBM + 8 * (size_t)k * SBM;
+    const size_t lds = (size_t)SRING * 3 * (32 * NJ) * (32 * KS) + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)split_cap(k) * SBM + 8 * (size_t)k * SBM;
     static LdsGrant grant;  // per template instance
     if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NJ, KS, NCH>), lds, grant)) return rc;
     const int64_t blocks = (m + SBM - 1) / SBM;
