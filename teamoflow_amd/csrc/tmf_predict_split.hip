@@ -19,6 +19,7 @@
 // (per-row threshold in registers, pending buffer, one lane per row merges).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/tmf.h"
 #include "tmf_common.h"
@@ -31,8 +32,12 @@ typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_s;
 typedef __attribute__((address_space(1))) const void gbl_void_s;
 
-constexpr int SBM = 256, SMAXK = 32, SMAXR = 128, SRING = 3;
-__host__ __device__ constexpr int split_cap(int k) { return k <= 16 ? 16 : 8; }   // pending entries per row: what the LDS leaves next to the lists
+constexpr int SMAXK = 32, SMAXR = 128;
+// Two shapes of workgroup.  WAVES = 4 (128 users, 2-slot ring, two workgroups per CU, k <= 16): the workgroups of a CU drift
+// apart, so one multiplies while the other stands at its chunk barrier or files candidates - the two waves of a SIMD no longer
+// stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop, for k > 16
+// where two sets of lists do not fit the LDS.  Pending entries per row: what the LDS leaves next to the lists.
+__host__ __device__ constexpr int split_cap(int waves, int k) { return waves == 4 ? (k <= 12 ? 16 : 8) : (k <= 16 ? 16 : 8); }
 constexpr int kSplitRowsPad = 128;   // the item planes are padded to a multiple of this many rows (a multiple of every tile width)
 
 __device__ __forceinline__ bool before_s(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -90,17 +95,19 @@ __global__ __launch_bounds__(256) void k_split3_rows(const float* __restrict__ X
 // (NJ, KS) = (4, 2): 128-item tiles, 64 accumulator registers - narrow tables, where the A fragments are few;
 //            (2, 4):  64-item tiles, 32 accumulator registers - leaves room for the 96 A registers of r = 128 without spills.
 // Either way a chunk is 512 16-byte pieces per plane (one per thread) and 48 MFMAs per wave between two barriers.
-template <int NJ, int KS, int NCH>
-__global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __restrict__ A, const __bf16* __restrict__ Bp,
+template <int NJ, int KS, int NCH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk_split(const float* __restrict__ A, const __bf16* __restrict__ Bp,
                                                                int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda, int k,
                                                                int clamp, int32_t* __restrict__ out_idx,
                                                                float* __restrict__ out_val) {
     constexpr int LDP = 16 * KS * NCH, SBN = 32 * NJ, SROW = 32 * KS /* bytes, unpadded: the image is written by LDS-DMA */, SPLANE = SBN * SROW, SSLOT = 3 * SPLANE;
     constexpr int NK = KS * NCH;   // k-steps per plane
+    constexpr int SBM = 32 * WAVES, THREADS = 64 * WAVES, SRING = WAVES == 4 ? 2 : 3;
+    constexpr int LPW = 8 / WAVES;   // LDS-DMA loads per plane, chunk and wave
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* Bs = smem_raw;                                               // [SRING slots][3 planes][SBN][SROW] bytes
     float* tau = reinterpret_cast<float*>(Bs + SRING * SSLOT);         // [SBM]
-    const int SCAP = split_cap(k);
+    const int SCAP = split_cap(WAVES, k);
     int* cnt = reinterpret_cast<int*>(tau + SBM);                      // [SBM]
     float* pend_v = reinterpret_cast<float*>(cnt + SBM);               // [SCAP][SBM]
     int* pend_i = reinterpret_cast<int*>(pend_v + SCAP * SBM);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
             }
         }
     }
-    for (int t = tid; t < SBM; t += 512) {
+    for (int t = tid; t < SBM; t += THREADS) {
         tau[t] = (row0 + t < m) ? -INFINITY : INFINITY;
         cnt[t] = 0;
         for (int j = 0; j < k; ++j) { list_v[j * SBM + t] = -INFINITY; list_i[j * SBM + t] = 0x7fffffff; }
@@ -151,9 +158,13 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
     // row's piece q ^ swz(i), swz(i) = (i / (16 / SR)) % SR, which spreads the pieces that 16 consecutive rows read together
     // over all 16 bank slots; the operand reads apply the same XOR.
     constexpr int SR = 2 * KS, RW = 64 / SR;
-    static_assert(8 * RW == SBN, "eight waves fill one plane of a tile");
-    const int s_row = RW * wave + lane / SR;
-    const int s_piece = (lane % SR) ^ ((s_row / (16 / SR)) % SR);
+    static_assert(8 * RW == SBN, "eight wave-instructions fill one plane of a tile");
+    int s_off[LPW];   // element offset of this lane's source piece in row group i of the wave (rows RW LPW wave + RW i + lane / SR)
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int row = RW * (LPW * wave + i) + lane / SR;
+        s_off[i] = row * LDP + 8 * ((lane % SR) ^ ((row / (16 / SR)) % SR));
+    }
     const int ntiles = (int)((n + SBN - 1) / SBN);
     const int nchunks = ntiles * NCH;
     // Warm-up: the first `warm` tiles are multiplied twice.  The first time only a running maximum per (row, lane) is kept -
@@ -164,26 +175,27 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
     const int warm = (k <= 16 && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
     const int warm_chunks = warm * NCH;
     const int64_t plane = n_pad * LDP;
-    const __bf16* src0 = Bp + (int64_t)s_row * LDP + 8 * s_piece;
     auto g_issue = [&](int g, int slot) {   // chunk g -> ring slot `slot` (three LDS-DMA loads per wave)
         int gg = g < warm_chunks ? g : g - warm_chunks;
         gg = gg < nchunks ? gg : nchunks - 1;   // the read-ahead past the last chunk re-reads it
-        const __bf16* s = src0 + (int64_t)(gg / NCH) * (SBN * LDP) + 16 * KS * (gg % NCH);
-        char* dst = Bs + slot * SSLOT + wave * 1024;
+        const __bf16* s = Bp + (int64_t)(gg / NCH) * (SBN * LDP) + 16 * KS * (gg % NCH);
+        char* dst = Bs + slot * SSLOT + wave * (1024 * LPW);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_void_s*)(s + p * plane), (lds_void_s*)(dst + p * SPLANE), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < LPW; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void_s*)(s + p * plane + s_off[i]), (lds_void_s*)(dst + p * SPLANE + i * 1024), 16, 0, 0);
     };
     // Chunk g + 2 is issued at the top of iteration g into the slot read in iteration g - 1 (every wave passed the barrier
     // that ended it).  At the bottom a counted wait leaves only those three loads in flight - chunk g + 1 has landed - and
     // the raw barrier publishes it to the readers of iteration g + 1 (a __syncthreads() would drain the DMA queue).
     auto ring_step = [&]() {
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SRING - 2) * 3 * LPW) : "memory");
         __builtin_amdgcn_s_barrier();
     };
     __syncthreads();   // lists and thresholds initialised; no DMA in flight yet
     g_issue(0, 0);
-    g_issue(1, 1);
+    if (SRING == 3) g_issue(1, 1);
     ring_step();
     const int rd_swz = (l31 / (16 / SR)) % SR;   // swz(32 j + l31) for every column block j
 
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c, ++g) {
-            g_issue(g + 2, slot == 0 ? 2 : slot - 1);
+            g_issue(g + SRING - 1, slot == 0 ? SRING - 1 : slot - 1);
             const char* bs = Bs + slot * SSLOT + l31 * SROW;
             int po[KS];   // byte offset of this lane's piece of k-step ks inside its row
 #pragma unroll
@@ -372,17 +384,36 @@ __global__ __launch_bounds__(512, 1) void k_predict_topk_split(const float* __re
 static int64_t split_rows_pad(int64_t n) { return (n + kSplitRowsPad - 1) / kSplitRowsPad * kSplitRowsPad; }
 static int split_ldp(int r) { return r <= 32 ? 32 : r <= 64 ? 64 : 128; }
 
-template <int NJ, int KS, int NCH>
-static int launch_predict_topk_split(const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
+template <int NJ, int KS, int NCH, int WAVES>
+static int launch_predict_topk_split_w(const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
                                      int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
-    const size_t lds = (size_t)SRING * 3 * (32 * NJ) * (32 * KS) + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)split_cap(k) * SBM + 8 * (size_t)k * SBM;
+    constexpr int SBM = 32 * WAVES, SRING = WAVES == 4 ? 2 : 3;
+    const size_t lds = (size_t)SRING * 3 * (32 * NJ) * (32 * KS) + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)split_cap(WAVES, k) * SBM + 8 * (size_t)k * SBM;
     static LdsGrant grant;  // per template instance
-    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NJ, KS, NCH>), lds, grant)) return rc;
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NJ, KS, NCH, WAVES>), lds, grant)) return rc;
     const int64_t blocks = (m + SBM - 1) / SBM;
-    TMF_REQUIRE_LAUNCH(blocks, 512, "predict_topk_split");
-    hipLaunchKernelGGL((k_predict_topk_split<NJ, KS, NCH>), dim3((unsigned)blocks), dim3(512), lds, stream, A, Bp, m, n, n_pad, K, lda, k,
+    TMF_REQUIRE_LAUNCH(blocks, 64 * WAVES, "predict_topk_split");
+    hipLaunchKernelGGL((k_predict_topk_split<NJ, KS, NCH, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, A, Bp, m, n, n_pad, K, lda, k,
                        clamp, out_idx, out_val);
     return check_launch("tmf_predict_topk_split_f32");
+}
+
+static int split_waves(int k) {   // TMF_SPLIT_WAVES=4|8 overrides (A/B runs)
+    static const int forced = [] { const char* e = getenv("TMF_SPLIT_WAVES"); return e ? atoi(e) : 0; }();
+    if (forced == 8 || k > 16) return 8;
+    return 4;
+}
+
+static int launch_predict_topk_split(int ldp, int k, const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K,
+                                     int64_t lda, int clamp, int32_t* out_idx, float* out_val, hipStream_t s) {
+    const bool w4 = split_waves(k) == 4;
+#define TMF_SPLIT_GO(NJ, KS, NCH)                                                                                              \
+    return w4 ? launch_predict_topk_split_w<NJ, KS, NCH, 4>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, s)         \
+              : launch_predict_topk_split_w<NJ, KS, NCH, 8>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, s)
+    if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
+    if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
+    TMF_SPLIT_GO(2, 4, 2);
+#undef TMF_SPLIT_GO
 }
 
 }  // namespace tmf
@@ -422,7 +453,5 @@ extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_
         hipLaunchKernelGGL(tmf::k_split3_rows, dim3((unsigned)blocks), dim3(256), 0, s, B, n, r, ldb, Bp, n_pad, ldp);
         if (int rc = tmf::check_launch("tmf_predict_topk_split_f32 (item planes)")) return rc;
     }
-    if (ldp == 32) return tmf::launch_predict_topk_split<4, 2, 1>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
-    if (ldp == 64) return tmf::launch_predict_topk_split<4, 2, 2>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
-    return tmf::launch_predict_topk_split<2, 4, 2>(A, Bp, m, n, n_pad, r, lda, k, clamp_negatives, out_idx, out_val, s);
+    return tmf::launch_predict_topk_split(ldp, k, A, Bp, m, n, n_pad, r, lda, clamp_negatives, out_idx, out_val, s);
 }
