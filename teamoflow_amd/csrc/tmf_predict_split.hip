@@ -40,6 +40,14 @@ constexpr int SMAXK = 32, SMAXR = 128;
 __host__ __device__ constexpr int split_cap(int waves, int k) { return waves == 4 ? (k <= 12 ? 16 : 8) : (k <= 16 ? 16 : 8); }
 constexpr int kSplitRowsPad = 128;   // the item planes are padded to a multiple of this many rows (a multiple of every tile width)
 
+// max of two accumulator values without the canonicalising v_max(x, x) hipcc puts in front of fmaxf (NaNs do not matter here:
+// a NaN score never compares above a threshold)
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ bool before_s(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
 // x -> (x1, x2, x3) with x1 + x2 + x3 == x exactly for every finite x whose residuals stay normal.  A value that rounds to
@@ -225,8 +233,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
         for (int q = 0; q < 16; ++q) {
             float mx = acc[0][q];
 #pragma unroll
-            for (int j = 1; j < NJ; ++j) mx = fmaxf(mx, acc[j][q]);
-            if (clamp) mx = fmaxf(mx, 0.f);
+            for (int j = 1; j < NJ; ++j) mx = max_raw(mx, acc[j][q]);
+            if (clamp) mx = max_raw(mx, 0.f);
             pass |= (mx > tq[q]) ? (1u << q) : 0u;
         }
         return pass;
@@ -311,6 +319,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
 #pragma unroll
             for (int st = 0; st < KS * NJ; ++st) {   // st = NJ ks + j
                 const int ks = st / NJ, j = st % NJ;
+                const bf16x8_s* b = bq[st & 1];
+                const int kk = KS * c + ks;
+                // The operands of step st + 1 are requested BEHIND the first MFMA of step st: the only wait hipcc places is a
+                // full lgkmcnt(0) in front of a step's first MFMA, which then covers nothing newer than the operands it needs
+                // (requested five MFMAs = 160 cycles earlier); requested in front of step st they sat behind that wait.
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[kk], b[0], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < KS * NJ) {
                     const int ks1 = (st + 1) / NJ, j1 = (st + 1) % NJ;
 #pragma unroll
@@ -318,9 +333,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
                         bq[(st + 1) & 1][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + 32 * j1 * SROW + po[ks1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8_s* b = bq[st & 1];
-                const int kk = KS * c + ks;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[kk], b[0], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[2], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[kk], b[1], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[kk], b[0], acc[j], 0, 0, 0);
@@ -336,9 +348,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
             for (int q = 0; q < 16; ++q) {
                 float mx = acc[0][q];
 #pragma unroll
-                for (int j = 1; j < NJ; ++j) mx = fmaxf(mx, acc[j][q]);
-                if (clamp) mx = fmaxf(mx, 0.f);
-                tq[q] = fmaxf(tq[q], mx);
+                for (int j = 1; j < NJ; ++j) mx = max_raw(mx, acc[j][q]);
+                if (clamp) mx = max_raw(mx, 0.f);
+                tq[q] = max_raw(tq[q], mx);
             }
             continue;
         }
