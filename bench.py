@@ -216,11 +216,12 @@ PMC_LEG_FILES = {'c4_mse': os.path.join(ROOT, 'profiles', 'pmc_c4_mse_latest.jso
 
 def csrc_sha():
     """Fingerprint of the kernel sources a PMC profile belongs to (tools/profile_summary.py stamps the same value): every
-    source of the TRAINING path - kernels, index preparation, shared header, the ABI.  tmf_predict.hip (ranking only: none of its
-    kernels runs in a profiled epoch) is left out, so that a change there does not orphan the training profiles."""
+    source of the TRAINING path - kernels, index preparation, shared header, the ABI.  tmf_predict.hip and tmf_predict_split.hip
+    (ranking only: none of their kernels runs in a profiled epoch) are left out, so that a change there does not orphan the
+    training profiles."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'teamoflow_amd', 'csrc')
-    files = sorted(f for f in os.listdir(d) if f.endswith(('.hip', '.h')) and f != 'tmf_predict.hip')
+    files = sorted(f for f in os.listdir(d) if f.endswith(('.hip', '.h')) and f not in ('tmf_predict.hip', 'tmf_predict_split.hip'))
     for path in [os.path.join(d, f) for f in files] + [os.path.join(ROOT, 'include', 'tmf.h')]:
         h.update(open(path, 'rb').read())
     return h.hexdigest()[:16]
@@ -827,17 +828,38 @@ def main():
         # predict rows/s: stable top-10 over the full catalog, fused GEMM + top-k (no [m, n] matrix)
         Ue, Ve = wl.st.U[:, :wl.r], wl.st.V[:wl.n, :wl.r]
         rows = min(wl.m, 262144)
-        _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+
+        def time_topk(arith):
+            _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True, arithmetic=arith)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True, arithmetic=arith)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        dt = time_topk('fp32' if args.dtype != 'bf16' else None)
         out['predict_rows_per_sec'] = rows / dt
         out['predict_tflops'] = 2.0 * rows * wl.n * wl.r / dt / 1e12
         out['predict_note'] = (f'stable top-10 of U.V^T over all {wl.n} items for {rows} users, fused MFMA GEMM + top-k '
                                + ('(tmf_predict_topk_bf16: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)' if args.dtype == 'bf16'
                                   else '(tmf_predict_topk_f32: exact-fp32 MFMA, peak 157.3 TF)'))
+        if args.dtype != 'bf16' and _ops.split_topk_supported(wl.r, 10):
+            # the same ranking on the bf16 matrix cores, fp32-accurate: three exact bf16 planes per factor, six plane products,
+            # fp32 accumulation (tmf_predict_topk_split_f32) - what model.retrieve_user_recs / recall_at_k run at this size
+            dts = time_topk('split')
+            sample = min(rows, 2048)
+            ref = (Ue[:sample].double() @ Ve.double().T).clamp_min(0)
+            norm = float(ref.abs().max())
+            err = {}
+            for arith in ('fp32', 'split'):
+                v, i = _ops.predict_topk(Ue[:sample], Ve, 10, clamp_negatives=True, return_values=True, arithmetic=arith)
+                err[arith] = float((v.double() - torch.gather(ref, 1, i.long())).abs().max()) / max(norm, 1e-30)
+            del ref
+            out['predict_split'] = dict(rows_per_sec=rows / dts, tflops_fp32_equivalent=2.0 * rows * wl.n * wl.r / dts / 1e12,
+                                        bf16_mfma_tflops=12.0 * rows * wl.n * wl.r / dts / 1e12, over_fp32_kernel=dt / dts,
+                                        max_abs_err_over_max_score_vs_fp64=err, err_sample_users=sample,
+                                        note='fp32 factors split exactly into 3 bf16 planes, 6 plane products on v_mfma_f32_32x32x16_bf16, '
+                                             'fp32 accumulate: fp32-accurate (errors vs an fp64 product listed beside the fp32 kernel\'s); '
+                                             'dense bf16 peak ~2500 TF = 417 TF fp32-equivalent; default of the class surface at this size')
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want),
                                    case='C1 golden fixture: ranking of the oracle-trained tables (450 epochs)')

@@ -45,7 +45,8 @@ def predict_gemm(user_embedding, item_embedding, out=None):
 
 
 FUSED_MAX_K, FUSED_MAX_K_BF16, FUSED_MAX_R, FUSED_MAX_R_BF16 = 64, 32, 256, 256
-SPLIT_BY_DEFAULT = False   # whether arithmetic='auto' takes the three-plane bf16 split where it applies
+SPLIT_MIN_SCORES = 1 << 26   # arithmetic='auto' takes the three-plane bf16 split from this many scores (m * n) on: below, the pass that
+                             # splits the item table and its workspace are not worth it and the fp32 MFMA kernel answers
 SORT_MAX_ELEMS = 1 << 29   # elements ranked per call of the wide-row path (2 GB of keys + 2 GB of ids, twice)
 
 
@@ -77,7 +78,8 @@ def split_topk_supported(r, k):
 def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False, arithmetic=None):
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
     fp32 tables: fp32 MFMA (k <= 64, width <= 256), or - arithmetic='split', width <= 128, k <= 32 - the fp32-accurate
-    three-plane bf16 split on the bf16 MFMA (tmf_predict_topk_split_f32); 'auto' takes the split kernel where it applies.
+    three-plane bf16 split on the bf16 MFMA (tmf_predict_topk_split_f32: ~1.9x the rate, errors against fp64 at or below the fp32
+    kernel's); 'auto' takes the split kernel where it applies and the job has SPLIT_MIN_SCORES scores or more.
     bf16 tables (both operands): bf16 MFMA with fp32 accumulation, k <= 32, width <= 256.
     See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
@@ -109,7 +111,7 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
     if arithmetic == 'split' and not split_topk_supported(r, k):
         raise ValueError(f'the split kernel supports widths <= 128 and k <= 32 (got {r}, {k})')
-    if arithmetic == 'split' or (arithmetic == 'auto' and SPLIT_BY_DEFAULT and split_topk_supported(r, k)):
+    if arithmetic == 'split' or (arithmetic == 'auto' and m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k)):
         need = lib.tmf_predict_topk_split_workspace_bytes(n, r)
         ws = torch.empty(need, dtype=torch.uint8, device=A.device)
         _lib.check(lib.tmf_predict_topk_split_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),

@@ -9,14 +9,21 @@
 // of one fp32 MFMA of the same shape on gfx950 (2.5 PFLOP/s against 157 TFLOP/s dense), so the fp32-equivalent ceiling of
 // this kernel is 2.7 x the fp32 MFMA peak.
 //
-// Structure: that of k_predict_topk_bf16 (tmf_predict.hip).  512 threads = 8 waves own 256 users, 32 per wave; the users'
-// rows are split in registers at load time and stay there as A fragments of the three planes (3 x K/16 x 4 VGPRs per lane).
-// The item table is split once per call into a caller-provided workspace ([3][n_pad][32 NCH] bf16, zero padded), and item
-// tiles of 128 (64 at r > 64) stream through a 2-slot LDS ring in k-chunks of 32 (64): [plane][item][64 B of data + 16 B pad] - an 80-byte row
-// pitch puts 16 consecutive rows on 16 different 16-byte bank slots (5 i mod 16), so the ds_read_b128 operand reads are
-// conflict-free.  Per (k-step, 32-column block) a wave reads three B fragments and issues six MFMAs: half an LDS read per
-// MFMA, where the one-plane bf16 kernel needs one.  Candidates reach the rows' sorted lists as in the bf16 kernel
-// (per-row threshold in registers, pending buffer, one lane per row merges).
+// Structure: that of k_predict_topk_bf16 (tmf_predict.hip).  A workgroup owns 32 users per wave; the users' rows are split
+// in registers at load time and stay there as A fragments of the three planes (3 x K/16 x 4 VGPRs per lane: 96 at r = 128).
+// The item table is split once per call into a caller-provided workspace ([3][n_pad][K_PAD] bf16, zero padded), and item
+// tiles of 128 (64 at r > 64) stream through an LDS ring in k-chunks of 32 (64) by LDS-DMA - no staging registers, a counted
+// vmcnt and a raw barrier per chunk; the unpadded image is swizzled on the source side so that the ds_read_b128 operand
+// reads are conflict-free.  Per (k-step, 32-column block) a wave reads three B fragments and issues six MFMAs: half an LDS
+// read per MFMA, where the one-plane bf16 kernel needs one.  Candidates reach the rows' sorted lists as in the bf16 kernel
+// (per-row threshold in registers, pending buffer, one lane per row merges) but without LDS atomics, and a warm-up pass over
+// the first 1/64 of the catalog gives every row a threshold to start from.
+//
+// Measured (262144 x 100000, k = 10, random factors; tools/split_time.py, profiles/r03_predict_split.txt): r = 128: 29.9 ms =
+// 224.7 TF fp32-equivalent = 1.35 PFLOP/s of bf16 MFMA work (fp32 MFMA kernel: 57 ms, 118 TF); r = 64: 195 TF; r = 32: 149 TF.
+// Timing-only variants of the r = 128 run: without the candidate handling 27.3 ms, also without the chunk barrier 28.4 (no
+// gain: the barrier is not what the loop waits for), without the item loads 24.3 ms - the MFMA + operand-read loop itself runs
+// at ~75 % of the matrix pipe, which is where the guide's best bf16 GEMM templates sit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -356,12 +363,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
         }
         const int col0 = tile * SBN;
         const unsigned pass = prefilter();
-#ifdef TMF_SPLIT_NOCAND
-        if (k < 0 && __any(pass != 0u))
-#else
-        if (__any(pass != 0u))
-#endif
-        {  // candidates are appended; lists and thresholds catch up when a buffer is half full
+        if (__any(pass != 0u)) {  // candidates are appended; lists and thresholds catch up when a buffer is half full
             offer(col0, -1, pass);
             const int my_row = 32 * wave + l31;
             const int c_now = (h == 0) ? cnt[my_row] : 0;
