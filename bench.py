@@ -392,6 +392,13 @@ class Workload:
     def __init__(self, args, m, n, nnz_target, r, S, loss, dtype, rank, world, dev, strong=False):
         self.n, self.r, self.S, self.loss, self.dtype = n, r, S, loss, dtype
         t0 = time.perf_counter()
+
+        def trace(what):   # TMF_BENCH_TRACE=1: where every rank is in its preparation (stderr)
+            if os.environ.get('TMF_BENCH_TRACE') == '1':
+                torch.cuda.synchronize()
+                log(f'[bench rank {rank}] {what} at {time.perf_counter() - t0:.1f} s, {torch.cuda.memory_allocated() / 2**30:.1f} GiB allocated, '
+                    f'{torch.cuda.memory_reserved() / 2**30:.1f} GiB reserved')
+        trace('start')
         n_pad = tdist.padded_rows(n, world)
         if strong and world > 1:
             # the ONE global problem, cut into contiguous user blocks of balanced cost (interactions + negatives)
@@ -403,6 +410,7 @@ class Workload:
             idx, val = _engine.take_interactions(idx, val, keep, user_offset=b)
             U0 = init_table(m, r, 11, dev)[b:e].clone()
             self.user_block, m = (b, e), e - b
+            trace('interactions of the global problem cut')
         else:
             idx, val = gen_interactions(m, n, nnz_target, args.item_dist, rank, dev)
             U0 = init_table(m, r, 11 + rank, dev)
@@ -416,6 +424,7 @@ class Workload:
         self.plan = _engine.InteractionPlan(idx, val, m, n_pad, user_chunks=_engine.mse_user_chunks() if loss == 'mse' else 1,
                                             csc=loss == 'mse')
         self.wplan, self.R = None, None
+        trace('interaction plan built')
         if loss == 'wmrb':
             if strong and world > 1:
                 # the ONE problem: its negative table is the table of the N = 1 run (seed 100), of which this rank keeps its users' rows
@@ -423,12 +432,15 @@ class Workload:
                 self.R = random_sampler_device(n, args.users, S, seed=100, device=dev)[b:e].contiguous()
             else:
                 self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
+            trace('negative table drawn')
             ns, sliced = _engine.choose_wmrb_user_pass(m, n, _lib.padded_ld(r, torch.bfloat16) if dtype == 'bf16' else ld, S, self.plan.n_pos, r,
                                                        elem_size=2 if dtype == 'bf16' else 4)
             rows4 = _engine.rows4_wanted(r, torch.bfloat16 if dtype == 'bf16' else torch.float32, self.plan, self.R)
             self.wplan = _engine.WmrbPlan(self.plan, self.R, user_chunks=_engine.default_user_chunks(m, ld, n_items=None if rows4 else n),
                                           item_slices=ns, n_components=r, sliced=sliced, rows4=rows4)
+        trace('WMRB plan built')
         self.st = _engine.TrainState(U0, V0, self.plan, r, self.wplan, dtype=torch.bfloat16 if dtype == 'bf16' else torch.float32)
+        trace('training state allocated')
         self.adam = _engine.adam_constants(args.lr)
         self.c = n / S
         torch.cuda.synchronize()
