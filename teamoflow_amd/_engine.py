@@ -310,6 +310,22 @@ def fused_user_pass_fits(n_samples, n_components):
     return bool(_lib.load_library().tmf_wmrb_user_pass_fits(int(n_samples), min(int(n_components), 1024)))
 
 
+HINGE_CHUNK = 128   # interactions the hinge kernel ranks per pass (csrc/tmf_hinge.hip)
+
+
+def hinge_user_order(rowptr_u):
+    """Order in which the hinge kernel's waves take the users: by passes over their interactions (ceil(degree / 128)),
+    most first, users of equal cost in their natural order (the bulk - one pass - keeps streaming its rows in sequence).
+    None when no user needs a second pass.  Speed only (tmf_wmrb_hinge2_ordered)."""
+    if os.environ.get('TMF_HINGE_ORDER', '1') == '0':
+        return None
+    deg = rowptr_u[1:] - rowptr_u[:-1]
+    passes = (deg + (HINGE_CHUNK - 1)) // HINGE_CHUNK
+    if passes.numel() == 0 or int(passes.max()) <= 1:
+        return None
+    return torch.argsort(passes, descending=True, stable=True).to(torch.int32)
+
+
 class WmrbPlan:
     """Index structures of a WMRB fit, built once from the interactions and the static negative table.
 
@@ -401,6 +417,7 @@ class WmrbPlan:
             self.seg_e = SegmentTable(self.rowptr_e, chunk)
         self.wbuf = torch.zeros(E, dtype=torch.float32, device=dev)
         self.delta = self.wbuf[:nnz]
+        self.hinge_order = hinge_user_order(plan.rowptr_u)
         self.D = self.wbuf[nnz:].view(m, S)
         self._lists = None
 
@@ -597,8 +614,9 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None, user_epi=_lib.EPI_ADAM, 
             prof.stop(name)
     timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores3' + st.sfx)(lists, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp),
                                                                             _lib.ptr(st.pk), r, s))
-    timed('wmrb_hinge', lambda: lib.tmf_wmrb_hinge2(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(st.pk), _lib.ptr(st.sp),
-                                                    i32(m), i32(S), c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part), s))
+    timed('wmrb_hinge', lambda: lib.tmf_wmrb_hinge2_ordered(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(st.pk), _lib.ptr(st.sp),
+                                                            i32(m), i32(S), c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part),
+                                                            _lib.ptr(w.hinge_order), s))
     if st.row_stationary:
         # gradU + finish in one row-stationary kernel (lane groups own users and walk the slices; no partial rows)
         timed('wmrb_gradu', lambda: getattr(lib, 'tmf_wmrb_gradu4' + st.sfx)(

@@ -75,6 +75,7 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_user_pass_fits': (_I, [_I32, _I]),
     'tmf_wmrb_scores3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_hinge2': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P]),
+    'tmf_wmrb_hinge2_ordered': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P]),
     'tmf_wmrb_gradu3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _I, _P]),
     'tmf_wmrb_gradu4_supported': (_I, [_I, _I]),
     'tmf_wmrb_gradu4_workspace_bytes': (_SZ, [_I32, _I32, _I32]),

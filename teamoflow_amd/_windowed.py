@@ -114,9 +114,9 @@ class WindowedHipBackend:
         """WMRB: hinge step over the complete scores -> delta, D, per-user loss."""
         lib, p, w = _lib.get(), self.plan, self.wplan
         i32 = ctypes.c_int32
-        _lib.check(lib.tmf_wmrb_hinge2(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(self.pk), _lib.ptr(self.sp), i32(self.m),
-                                       i32(w.S), self.c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(self.loss_part),
-                                       _lib.stream_ptr()), lib)
+        _lib.check(lib.tmf_wmrb_hinge2_ordered(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(self.pk), _lib.ptr(self.sp), i32(self.m),
+                                               i32(w.S), self.c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(self.loss_part),
+                                               _lib.ptr(getattr(w, 'hinge_order', None)), _lib.stream_ptr()), lib)
 
     def grads_window(self, t, Vwin, out):
         """Adds the window's part of the user gradient to layer 0 of ``part`` and writes the raw item gradient of the

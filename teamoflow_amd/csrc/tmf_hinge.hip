@@ -86,11 +86,15 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ spu, int s0,
 __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
     const int64_t* __restrict__ rowptr, const float* __restrict__ val, const float* __restrict__ p,
     const float* __restrict__ sp, int S, int fixbits, float c, int64_t n_users, float* __restrict__ delta,
-    float* __restrict__ D, float* __restrict__ loss_part) {
+    float* __restrict__ D, float* __restrict__ loss_part, const int32_t* __restrict__ order) {
     __shared__ HingeLds lds_all[HWAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t u = (int64_t)blockIdx.x * HWAVES + wave;
-    if (u >= n_users) return;
+    const int64_t slot = (int64_t)blockIdx.x * HWAVES + wave;
+    if (slot >= n_users) return;
+    // `order` (optional): the users in the order the waves should take them - the heavy ones first, so that the one user with
+    // twenty chunks of interactions does not start last and finish alone.  Every user is computed by itself; the order
+    // changes no result.
+    const int64_t u = order ? (int64_t)order[slot] : slot;
     HingeLds& L = lds_all[wave];
     const int64_t rb = rowptr[u], re = rowptr[u + 1];
     const float* spu = sp + u * (int64_t)S;
@@ -318,6 +322,12 @@ using namespace tmf;
 
 extern "C" int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
                                int32_t S, float c, float* delta, float* D, float* loss_part, void* stream) {
+    return tmf_wmrb_hinge2_ordered(rowptr, val, p, sp, n_users, S, c, delta, D, loss_part, nullptr, stream);
+}
+
+extern "C" int tmf_wmrb_hinge2_ordered(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
+                                       int32_t S, float c, float* delta, float* D, float* loss_part, const int32_t* user_order,
+                                       void* stream) {
     if (n_users == 0) return TMF_OK;
     TMF_REQUIRE(rowptr && sp && D && n_users > 0 && S > 0, "wmrb_hinge2: bad arguments");
     int lg = 0;  // ceil(log2 S)
@@ -325,6 +335,6 @@ extern "C" int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const fl
     const int fixbits = 62 - lg;  // S values below 2^fixbits each: their sum fits a signed 64-bit integer
     const unsigned blocks = (unsigned)(((int64_t)n_users + HWAVES - 1) / HWAVES);
     hipLaunchKernelGGL(k_wmrb_hinge2, dim3(blocks), dim3(64 * HWAVES), 0, (hipStream_t)stream, rowptr, val, p, sp, (int)S, fixbits,
-                       c, (int64_t)n_users, delta, D, loss_part);
+                       c, (int64_t)n_users, delta, D, loss_part, user_order);
     return check_launch("tmf_wmrb_hinge2");
 }

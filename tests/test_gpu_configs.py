@@ -221,6 +221,20 @@ def test_hinge_kernel_alone(tm, case):  # noqa: F811
     assert rel_err(got[0], r_delta) < 1e-5 and rel_err(got[1], r_D) < 1e-5
     assert np.abs(got[2] - r_loss).max() <= 1e-5 * max(np.abs(r_loss).max(), 1e-30)
     assert (got[0][~(val > 0)] == 0).all()
+    # the ordered launch (heavy users first: _engine.hinge_user_order) computes every user by itself: same bits
+    order = tm.engine.hinge_user_order(d_rowptr)
+    if case in ('chunks', 'ties', 'wide'):
+        assert order is not None and sorted(order.cpu().tolist()) == list(range(m))
+        heavy_first = np.asarray(degs)[order.cpu().numpy()]
+        assert (np.diff(-((heavy_first + 127) // 128)) >= 0).all()
+    for o in (order, torch.randperm(m, device='cuda').to(torch.int32)):
+        delta.fill_(7.0), D.fill_(7.0), loss.fill_(7.0)
+        tm.lib.check(lib.tmf_wmrb_hinge2_ordered(tm.lib.ptr(d_rowptr), tm.lib.ptr(d_val), tm.lib.ptr(d_p), tm.lib.ptr(d_sp),
+                                                 ctypes.c_int32(m), ctypes.c_int32(S_), c, tm.lib.ptr(delta), tm.lib.ptr(D),
+                                                 tm.lib.ptr(loss), tm.lib.ptr(o), tm.lib.stream_ptr()), lib)
+        torch.cuda.synchronize()
+        again = (delta[:nnz].cpu().numpy(), D.cpu().numpy(), loss.cpu().numpy())
+        assert all(np.array_equal(a, b) for a, b in zip(first, again))
 
 
 def test_slice_grids_beyond_one_launch(tm, monkeypatch):  # noqa: F811
