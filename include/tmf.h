@@ -210,7 +210,7 @@ int tmf_wmrb_scores3_bf16(const tmf_slice_lists* lists, const void* U, const voi
 int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
                     int32_t n_samples, float c, float* delta, float* D, float* loss_part, void* stream);
 /* The same with the order in which the waves take the users (a permutation of 0 .. n_users - 1, or NULL = 0, 1, 2 ...): a user
- * costs one pass per 128 interactions, so the few with thousands should start first, not last.  Speed only - every user is
+ * costs one pass per 255 interactions, so the few with thousands should start first, not last.  Speed only - every user is
  * computed by itself and the outputs do not depend on the order. */
 int tmf_wmrb_hinge2_ordered(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
                             int32_t n_samples, float c, float* delta, float* D, float* loss_part, const int32_t* user_order,

@@ -310,11 +310,11 @@ def fused_user_pass_fits(n_samples, n_components):
     return bool(_lib.load_library().tmf_wmrb_user_pass_fits(int(n_samples), min(int(n_components), 1024)))
 
 
-HINGE_CHUNK = 128   # interactions the hinge kernel ranks per pass (csrc/tmf_hinge.hip)
+HINGE_CHUNK = 255   # interactions the hinge kernel ranks per pass (csrc/tmf_hinge.hip: HCHUNK)
 
 
 def hinge_user_order(rowptr_u):
-    """Order in which the hinge kernel's waves take the users: by passes over their interactions (ceil(degree / 128)),
+    """Order in which the hinge kernel's waves take the users: by passes over their interactions (ceil(degree / 255)),
     most first, users of equal cost in their natural order (the bulk - one pass - keeps streaming its rows in sequence).
     None when no user needs a second pass.  Speed only (tmf_wmrb_hinge2_ordered)."""
     if os.environ.get('TMF_HINGE_ORDER', '1') == '0':

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_split3_rows(const float* __restrict__ X
 // NJ column blocks of 32 items per tile, KS k-steps of 16 per chunk, NCH chunks per tile: K_PAD = 16 KS NCH.
 // (NJ, KS) = (4, 2): 128-item tiles, 64 accumulator registers - narrow tables, where the A fragments are few;
 //            (2, 4):  64-item tiles, 32 accumulator registers - leaves room for the 96 A registers of r = 128 without spills.
-// Either way a chunk is 512 16-byte pieces per plane (one per thread) and 48 MFMAs per wave between two barriers.
+// Either way a chunk is eight 1-KB LDS-DMA pieces per plane and 48 MFMAs per wave between two barriers.
 template <int NJ, int KS, int NCH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk_split(const float* __restrict__ A, const __bf16* __restrict__ Bp,
                                                                int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda, int k,
