@@ -848,16 +848,25 @@ def main():
             _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True, arithmetic=arith)
             torch.cuda.synchronize()
             return time.perf_counter() - t1
-        dt = time_topk('fp32' if args.dtype != 'bf16' else None)
+        # what the class surface runs at this size (arithmetic='auto'): for fp32 tables of width <= 128 the three-plane bf16 split
+        # (tmf_predict_topk_split_f32: fp32-accurate ranking on the bf16 matrix cores), else the fp32 / bf16 MFMA kernels
+        dt = time_topk(None)
+        split_default = args.dtype != 'bf16' and _ops.split_topk_supported(wl.r, 10) and rows * wl.n >= _ops.SPLIT_MIN_SCORES
         out['predict_rows_per_sec'] = rows / dt
         out['predict_tflops'] = 2.0 * rows * wl.n * wl.r / dt / 1e12
-        out['predict_note'] = (f'stable top-10 of U.V^T over all {wl.n} items for {rows} users, fused MFMA GEMM + top-k '
-                               + ('(tmf_predict_topk_bf16: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)' if args.dtype == 'bf16'
-                                  else '(tmf_predict_topk_f32: exact-fp32 MFMA, peak 157.3 TF)'))
-        if args.dtype != 'bf16' and _ops.split_topk_supported(wl.r, 10):
-            # the same ranking on the bf16 matrix cores, fp32-accurate: three exact bf16 planes per factor, six plane products,
-            # fp32 accumulation (tmf_predict_topk_split_f32) - what model.retrieve_user_recs / recall_at_k run at this size
-            dts = time_topk('split')
+        out['predict_note'] = (f'stable top-10 of U.V^T over all {wl.n} items for {rows} users, fused MFMA GEMM + top-k, as '
+                               f'MatrixFactorization.retrieve_user_recs / recall_at_k run it: '
+                               + ('tmf_predict_topk_bf16 (bf16 tables: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)' if args.dtype == 'bf16'
+                                  else 'tmf_predict_topk_split_f32 (fp32 tables split exactly into 3 bf16 planes, 6 plane products on '
+                                       'v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-accurate; predict_tflops is fp32-EQUIVALENT, the bf16 MFMA work '
+                                       'is 6x that; dense bf16 peak ~2500 TF = 417 TF fp32-equivalent)' if split_default
+                                  else 'tmf_predict_topk_f32 (fp32 MFMA, peak 157.3 TF)'))
+        if args.dtype != 'bf16':
+            dt32 = time_topk('fp32') if split_default else dt
+            out['predict_fp32_mfma'] = dict(rows_per_sec=rows / dt32, tflops=2.0 * rows * wl.n * wl.r / dt32 / 1e12,
+                                            note='the same ranking by tmf_predict_topk_f32 (v_mfma_f32_32x32x2_f32, peak 157.3 TF): '
+                                                 "model.predict_arithmetic = 'fp32'")
+        if split_default:
             sample = min(rows, 2048)
             ref = (Ue[:sample].double() @ Ve.double().T).clamp_min(0)
             norm = float(ref.abs().max())
@@ -866,12 +875,10 @@ def main():
                 v, i = _ops.predict_topk(Ue[:sample], Ve, 10, clamp_negatives=True, return_values=True, arithmetic=arith)
                 err[arith] = float((v.double() - torch.gather(ref, 1, i.long())).abs().max()) / max(norm, 1e-30)
             del ref
-            out['predict_split'] = dict(rows_per_sec=rows / dts, tflops_fp32_equivalent=2.0 * rows * wl.n * wl.r / dts / 1e12,
-                                        bf16_mfma_tflops=12.0 * rows * wl.n * wl.r / dts / 1e12, over_fp32_kernel=dt / dts,
+            out['predict_split'] = dict(rows_per_sec=rows / dt, tflops_fp32_equivalent=2.0 * rows * wl.n * wl.r / dt / 1e12,
+                                        bf16_mfma_tflops=12.0 * rows * wl.n * wl.r / dt / 1e12, over_fp32_kernel=dt32 / dt,
                                         max_abs_err_over_max_score_vs_fp64=err, err_sample_users=sample,
-                                        note='fp32 factors split exactly into 3 bf16 planes, 6 plane products on v_mfma_f32_32x32x16_bf16, '
-                                             'fp32 accumulate: fp32-accurate (errors vs an fp64 product listed beside the fp32 kernel\'s); '
-                                             'dense bf16 peak ~2500 TF = 417 TF fp32-equivalent; default of the class surface at this size')
+                                        note='errors of the returned top-10 values against an fp64 product, the fp32 MFMA kernel beside the split kernel')
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want),
                                    case='C1 golden fixture: ranking of the oracle-trained tables (450 epochs)')
