@@ -325,6 +325,15 @@ size_t tmf_predict_topk_split_workspace_bytes(int64_t n, int r);
 int tmf_predict_topk_split_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
                                int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* The same ranking with TWO fp16 planes per factor and three plane products (h2 v1 + h1 v2 + h1 v1, fp32 accumulate): every
+ * user row is scaled by its own power of two and the item table by one, so that the planes sit in fp16's normal range; 22
+ * bits of every factor take part (all 24 with the three bf16 planes above), and a factor below ~1e-6 of its table's largest
+ * magnitude keeps fewer.  Values against fp64: at the fp32 MFMA kernel's error (csrc/tmf_predict_split.hip, tests).  Half the
+ * matrix-core work of the three-plane form.  Same limits (tmf_predict_topk_split_supported); its own workspace size. */
+size_t tmf_predict_topk_half2_workspace_bytes(int64_t n, int r);
+int tmf_predict_topk_half2_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
+                               int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

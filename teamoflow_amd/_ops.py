@@ -68,7 +68,7 @@ def fused_topk_supported(user_embedding, item_embedding, k):
     return k <= (FUSED_MAX_K_BF16 if bf16 else FUSED_MAX_K) and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
 
 
-PREDICT_ARITHMETIC = os.environ.get('TMF_PREDICT_ARITHMETIC', 'auto')   # 'auto' | 'fp32' | 'split'
+PREDICT_ARITHMETIC = os.environ.get('TMF_PREDICT_ARITHMETIC', 'auto')   # 'auto' | 'fp32' | 'split' | 'half2'
 
 
 def split_topk_supported(r, k):
@@ -84,8 +84,8 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
     arithmetic = arithmetic or PREDICT_ARITHMETIC
-    if arithmetic not in ('auto', 'fp32', 'split'):
-        raise ValueError(f"arithmetic={arithmetic!r}: expected 'auto', 'fp32' or 'split'")
+    if arithmetic not in ('auto', 'fp32', 'split', 'half2'):
+        raise ValueError(f"arithmetic={arithmetic!r}: expected 'auto', 'fp32', 'split' or 'half2'")
     if torch.is_tensor(user_embedding) and torch.is_tensor(item_embedding) and \
             user_embedding.dtype == torch.bfloat16 and item_embedding.dtype == torch.bfloat16:
         A, m, r, lda = _bf16_operand(_cuda(user_embedding))
@@ -109,8 +109,14 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
         raise ValueError(f'k={k} must be in [1, {n}]')
     idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
-    if arithmetic == 'split' and not split_topk_supported(r, k):
-        raise ValueError(f'the split kernel supports widths <= 128 and k <= 32 (got {r}, {k})')
+    if arithmetic in ('split', 'half2') and not split_topk_supported(r, k):
+        raise ValueError(f'the split kernels support widths <= 128 and k <= 32 (got {r}, {k})')
+    if arithmetic == 'half2':
+        need = lib.tmf_predict_topk_half2_workspace_bytes(n, r)
+        ws = torch.empty(need, dtype=torch.uint8, device=A.device)
+        _lib.check(lib.tmf_predict_topk_half2_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
+                                                  _lib.ptr(idx), _lib.ptr(vals), _lib.ptr(ws), need, _lib.stream_ptr()), lib)
+        return (vals, idx) if return_values else idx
     if arithmetic == 'split' or (arithmetic == 'auto' and m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k)):
         need = lib.tmf_predict_topk_split_workspace_bytes(n, r)
         ws = torch.empty(need, dtype=torch.uint8, device=A.device)

@@ -35,6 +35,8 @@ namespace tmf {
 
 typedef float f32x16_s __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_s __attribute__((ext_vector_type(8)));
+typedef unsigned int raw16_s __attribute__((ext_vector_type(4)));   // one 16-byte MFMA operand of either element type
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_s;
 typedef __attribute__((address_space(1))) const void gbl_void_s;
@@ -45,6 +47,8 @@ constexpr int SMAXK = 32, SMAXR = 128;
 // stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop, for k > 16
 // where two sets of lists do not fit the LDS.  Pending entries per row: what the LDS leaves next to the lists.
 __host__ __device__ constexpr int split_cap(int waves, int k) { return waves == 4 ? (k <= 12 ? 16 : 8) : (k <= 16 ? 16 : 8); }
+// LDS ring slots: the two-plane chunks of the fp16 form are small enough for three of them beside two workgroups' lists
+__host__ __device__ constexpr int split_ring(int waves, bool half2) { return (waves == 4 && !half2) ? 2 : 3; }
 constexpr int kSplitRowsPad = 128;   // the item planes are padded to a multiple of this many rows (a multiple of every tile width)
 
 // max of two accumulator values without the canonicalising v_max(x, x) hipcc puts in front of fmaxf (NaNs do not matter here:
@@ -67,6 +71,33 @@ __device__ __forceinline__ void split3(float x, __bf16& x1, __bf16& x2, __bf16& 
     const float r1 = x - (float)h;
     x2 = (__bf16)r1;
     x3 = (__bf16)(r1 - (float)x2);
+}
+
+// Two-plane fp16 split of x * scale (scale a power of two that puts the largest magnitude of the row / table into
+// [2^14, 2^15)): x = (h1 + h2) / scale to 22 bits, and to 2^-25 / scale absolutely where h2 is subnormal.  Non-finite values
+// keep their class in h1.
+__device__ __forceinline__ void split2h(float x, float scale, _Float16& h1, _Float16& h2) {
+    const float xs = x * scale;
+    h1 = (_Float16)xs;
+    h2 = __builtin_isfinite(xs) && __builtin_isfinite((float)h1) ? (_Float16)(xs - (float)h1) : (_Float16)0.0f;
+}
+
+// The power of two that scales a largest magnitude mx into [2^14, 2^15) (1 for mx == 0 or a non-finite mx)
+__device__ __forceinline__ float half_scale_for(float mx) {
+    if (!(mx > 0.f) || !__builtin_isfinite(mx)) return 1.f;
+    int e;
+    (void)frexpf(mx, &e);            // mx = f 2^e, f in [0.5, 1)
+    e = 15 - e;
+    e = e > 126 ? 126 : (e < -126 ? -126 : e);
+    return ldexpf(1.f, e);
+}
+
+template <bool HALF2>
+__device__ __forceinline__ f32x16_s mfma_planes(const raw16_s a, const raw16_s b, const f32x16_s c) {
+    if constexpr (HALF2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_s, a), __builtin_bit_cast(f16x8_s, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_s, a), __builtin_bit_cast(bf16x8_s, b), c, 0, 0, 0);
 }
 
 // The k-th largest of the 32 values a half-wave holds (one per lane), returned to every lane of the half.
@@ -106,25 +137,68 @@ __global__ __launch_bounds__(256) void k_split3_rows(const float* __restrict__ X
     *reinterpret_cast<bf16x8_s*>(out + 2 * plane + o) = p3;
 }
 
+// max |x| over rows [0, rows) x columns [0, r) -> *out (as the bits of a non-negative float: atomicMax on the integer)
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ X, int64_t rows, int r, int64_t ld, unsigned* __restrict__ out) {
+    float mx = 0.f;
+    const int64_t total = rows * r;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const float v = fabsf(X[(t / r) * ld + t % r]);
+        if (v > mx && __builtin_isfinite(v)) mx = v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __float_as_uint(mx));
+}
+
+// The two fp16 planes of the item table under the table-wide scale (from *absmax): [2][rows_pad][ldp], zero padded; the
+// scale itself goes to *scale_out for the epilogue of the top-k kernel.
+__global__ __launch_bounds__(256) void k_split2_rows(const float* __restrict__ X, int64_t rows, int r, int64_t ld,
+                                                     _Float16* __restrict__ out, int64_t rows_pad, int ldp,
+                                                     const unsigned* __restrict__ absmax, float* __restrict__ scale_out) {
+    const float scale = half_scale_for(__uint_as_float(*absmax));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const int groups = ldp / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows_pad * groups) return;
+    const int64_t row = t / groups;
+    const int c0 = (int)(t % groups) * 8;
+    f16x8_s p1, p2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (row < rows && c0 + e < r) ? X[row * ld + c0 + e] : 0.f;
+        _Float16 a, b;
+        split2h(x, scale, a, b);
+        p1[e] = a; p2[e] = b;
+    }
+    const int64_t plane = rows_pad * ldp, o = row * ldp + c0;
+    *reinterpret_cast<f16x8_s*>(out + o) = p1;
+    *reinterpret_cast<f16x8_s*>(out + plane + o) = p2;
+}
+
 // NJ column blocks of 32 items per tile, KS k-steps of 16 per chunk, NCH chunks per tile: K_PAD = 16 KS NCH.
 // (NJ, KS) = (4, 2): 128-item tiles, 64 accumulator registers - narrow tables, where the A fragments are few;
 //            (2, 4):  64-item tiles, 32 accumulator registers - leaves room for the 96 A registers of r = 128 without spills.
 // Either way a chunk is eight 1-KB LDS-DMA pieces per plane and 48 MFMAs per wave between two barriers.
-template <int NJ, int KS, int NCH, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk_split(const float* __restrict__ A, const __bf16* __restrict__ Bp,
+// HALF2: two fp16 planes per factor and three products (h2 v1 + h1 v2 + h1 v1) instead of three bf16 planes and six: every
+// user row is scaled by its own power of two and the item table by one (so that the planes sit in fp16's normal range); a
+// row's scores all carry the same factor, which the ranking ignores and the epilogue takes out of the values.
+template <int NJ, int KS, int NCH, int WAVES, bool HALF2>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk_split(const float* __restrict__ A, const uint16_t* __restrict__ Bp,
                                                                int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda, int k,
                                                                int clamp, int32_t* __restrict__ out_idx,
-                                                               float* __restrict__ out_val) {
-    constexpr int LDP = 16 * KS * NCH, SBN = 32 * NJ, SROW = 32 * KS /* bytes, unpadded: the image is written by LDS-DMA */, SPLANE = SBN * SROW, SSLOT = 3 * SPLANE;
+                                                               float* __restrict__ out_val, const float* __restrict__ item_scale) {
+    constexpr int NP = HALF2 ? 2 : 3;   // planes
+    constexpr int LDP = 16 * KS * NCH, SBN = 32 * NJ, SROW = 32 * KS /* bytes, unpadded: the image is written by LDS-DMA */, SPLANE = SBN * SROW, SSLOT = NP * SPLANE;
     constexpr int NK = KS * NCH;   // k-steps per plane
-    constexpr int SBM = 32 * WAVES, THREADS = 64 * WAVES, SRING = WAVES == 4 ? 2 : 3;
+    constexpr int SBM = 32 * WAVES, THREADS = 64 * WAVES, SRING = split_ring(WAVES, HALF2);
     constexpr int LPW = 8 / WAVES;   // LDS-DMA loads per plane, chunk and wave
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* Bs = smem_raw;                                               // [SRING slots][3 planes][SBN][SROW] bytes
     float* tau = reinterpret_cast<float*>(Bs + SRING * SSLOT);         // [SBM]
     const int SCAP = split_cap(WAVES, k);
     int* cnt = reinterpret_cast<int*>(tau + SBM);                      // [SBM]
-    float* pend_v = reinterpret_cast<float*>(cnt + SBM);               // [SCAP][SBM]
+    float* inv_scale = reinterpret_cast<float*>(cnt + SBM);            // [SBM] what the epilogue multiplies a row's values by
+    float* pend_v = inv_scale + SBM;                                   // [SCAP][SBM]
     int* pend_i = reinterpret_cast<int*>(pend_v + SCAP * SBM);
     float* list_v = reinterpret_cast<float*>(pend_i + SCAP * SBM);     // [k][SBM]
     int* list_i = reinterpret_cast<int*>(list_v + (size_t)k * SBM);
@@ -133,31 +207,65 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     const int h = lane >> 5, l31 = lane & 31;
     const int64_t row0 = (int64_t)blockIdx.x * SBM;
 
-    // A fragments of the three planes: a?[kk] = plane?(U[row0 + 32 wave + l31][16 kk + 8 h .. + 8))
-    bf16x8_s a1[NK], a2[NK], a3[NK];
+    // A fragments of the planes: a[p][kk] = plane p of U[row0 + 32 wave + l31][16 kk + 8 h .. + 8)
+    raw16_s a[NP][NK];
     {
         const int64_t r = row0 + 32 * wave + l31;
         const float* p = A + (r < m ? r : 0) * lda;
+        float x[NK][8];
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
-            float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = 0.f;
+            for (int e = 0; e < 8; ++e) x[kk][e] = 0.f;
             const int k0 = 16 * kk + 8 * h;
             if (r < m && k0 < K) {
                 if (k0 + 7 < K) {
                     const f32x4_s lo = *reinterpret_cast<const f32x4_s*>(p + k0), hi = *reinterpret_cast<const f32x4_s*>(p + k0 + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+                    for (int e = 0; e < 4; ++e) { x[kk][e] = lo[e]; x[kk][4 + e] = hi[e]; }
                 } else {
-                    for (int e = 0; e < 8; ++e) if (k0 + e < K) x[e] = p[k0 + e];
+                    for (int e = 0; e < 8; ++e) if (k0 + e < K) x[kk][e] = p[k0 + e];
                 }
             }
+        }
+        if constexpr (HALF2) {
+            float mx = 0.f;   // the row's largest finite magnitude: this lane's half of the k-slices, then the other half's
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                __bf16 u, v, w;
-                split3(x[e], u, v, w);
-                a1[kk][e] = u; a2[kk][e] = v; a3[kk][e] = w;
+            for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = fabsf(x[kk][e]);
+                    mx = (v > mx && __builtin_isfinite(v)) ? v : mx;
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float sc = half_scale_for(mx);
+            if (h == 0) inv_scale[32 * wave + l31] = 1.f / (sc * *item_scale);   // both powers of two: exact
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                f16x8_s p1, p2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 u, v;
+                    split2h(x[kk][e], sc, u, v);
+                    p1[e] = u; p2[e] = v;
+                }
+                a[0][kk] = __builtin_bit_cast(raw16_s, p1);
+                a[1][kk] = __builtin_bit_cast(raw16_s, p2);
+            }
+        } else {
+            if (h == 0) inv_scale[32 * wave + l31] = 1.f;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                bf16x8_s p1, p2, p3;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    __bf16 u, v, w;
+                    split3(x[kk][e], u, v, w);
+                    p1[e] = u; p2[e] = v; p3[e] = w;
+                }
+                a[0][kk] = __builtin_bit_cast(raw16_s, p1);
+                a[1][kk] = __builtin_bit_cast(raw16_s, p2);
+                a[2][kk] = __builtin_bit_cast(raw16_s, p3);
             }
         }
     }
@@ -193,10 +301,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     auto g_issue = [&](int g, int slot) {   // chunk g -> ring slot `slot` (three LDS-DMA loads per wave)
         int gg = g < warm_chunks ? g : g - warm_chunks;
         gg = gg < nchunks ? gg : nchunks - 1;   // the read-ahead past the last chunk re-reads it
-        const __bf16* s = Bp + (int64_t)(gg / NCH) * (SBN * LDP) + 16 * KS * (gg % NCH);
+        const uint16_t* s = Bp + (int64_t)(gg / NCH) * (SBN * LDP) + 16 * KS * (gg % NCH);
         char* dst = Bs + slot * SSLOT + wave * (1024 * LPW);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < LPW; ++i)
                 __builtin_amdgcn_global_load_lds((gbl_void_s*)(s + p * plane + s_off[i]), (lds_void_s*)(dst + p * SPLANE + i * 1024), 16, 0, 0);
@@ -205,7 +313,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     // that ended it).  At the bottom a counted wait leaves only those three loads in flight - chunk g + 1 has landed - and
     // the raw barrier publishes it to the readers of iteration g + 1 (a __syncthreads() would drain the DMA queue).
     auto ring_step = [&]() {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SRING - 2) * 3 * LPW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SRING - 2) * NP * LPW) : "memory");
         __builtin_amdgcn_s_barrier();
     };
     __syncthreads();   // lists and thresholds initialised; no DMA in flight yet
@@ -320,31 +428,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
             int po[KS];   // byte offset of this lane's piece of k-step ks inside its row
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) po[ks] = 16 * ((2 * ks + h) ^ rd_swz);
-            bf16x8_s bq[2][3];  // the three B planes of one (k-step, column block), one step ahead of their MFMAs
+            raw16_s bq[2][NP];  // the B planes of one (k-step, column block), one step ahead of their MFMAs
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + po[0]);
+            for (int p = 0; p < NP; ++p) bq[0][p] = *reinterpret_cast<const raw16_s*>(bs + p * SPLANE + po[0]);
 #pragma unroll
             for (int st = 0; st < KS * NJ; ++st) {   // st = NJ ks + j
                 const int ks = st / NJ, j = st % NJ;
-                const bf16x8_s* b = bq[st & 1];
+                const raw16_s* b = bq[st & 1];
                 const int kk = KS * c + ks;
                 // The operands of step st + 1 are requested BEHIND the first MFMA of step st: the only wait hipcc places is a
                 // full lgkmcnt(0) in front of a step's first MFMA, which then covers nothing newer than the operands it needs
                 // (requested five MFMAs = 160 cycles earlier); requested in front of step st they sat behind that wait.
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[kk], b[0], acc[j], 0, 0, 0);
+                acc[j] = mfma_planes<HALF2>(a[NP - 1][kk], b[0], acc[j]);   // the smallest product first
                 __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < KS * NJ) {
                     const int ks1 = (st + 1) / NJ, j1 = (st + 1) % NJ;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        bq[(st + 1) & 1][p] = *reinterpret_cast<const bf16x8_s*>(bs + p * SPLANE + 32 * j1 * SROW + po[ks1]);
+                    for (int p = 0; p < NP; ++p)
+                        bq[(st + 1) & 1][p] = *reinterpret_cast<const raw16_s*>(bs + p * SPLANE + 32 * j1 * SROW + po[ks1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[2], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[kk], b[1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[kk], b[0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kk], b[0], acc[j], 0, 0, 0);
+                if constexpr (HALF2) {
+                    acc[j] = mfma_planes<HALF2>(a[0][kk], b[1], acc[j]);
+                    acc[j] = mfma_planes<HALF2>(a[0][kk], b[0], acc[j]);
+                } else {
+                    acc[j] = mfma_planes<HALF2>(a[0][kk], b[2], acc[j]);
+                    acc[j] = mfma_planes<HALF2>(a[1][kk], b[1], acc[j]);
+                    acc[j] = mfma_planes<HALF2>(a[1][kk], b[0], acc[j]);
+                    acc[j] = mfma_planes<HALF2>(a[0][kk], b[1], acc[j]);
+                    acc[j] = mfma_planes<HALF2>(a[0][kk], b[0], acc[j]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             ring_step();
@@ -390,7 +503,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     if (tid < SBM && row0 + tid < m) {
         for (int j = 0; j < k; ++j) {
             out_idx[(row0 + tid) * k + j] = list_i[j * SBM + tid];
-            if (out_val) out_val[(row0 + tid) * k + j] = list_v[j * SBM + tid];
+            if (out_val) out_val[(row0 + tid) * k + j] = list_v[j * SBM + tid] * inv_scale[tid];
         }
     }
 }
@@ -398,18 +511,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
 static int64_t split_rows_pad(int64_t n) { return (n + kSplitRowsPad - 1) / kSplitRowsPad * kSplitRowsPad; }
 static int split_ldp(int r) { return r <= 32 ? 32 : r <= 64 ? 64 : 128; }
 
-template <int NJ, int KS, int NCH, int WAVES>
-static int launch_predict_topk_split_w(const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
-                                     int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
-    constexpr int SBM = 32 * WAVES, SRING = WAVES == 4 ? 2 : 3;
-    const size_t lds = (size_t)SRING * 3 * (32 * NJ) * (32 * KS) + sizeof(float) * SBM + sizeof(int) * SBM + 8 * (size_t)split_cap(WAVES, k) * SBM + 8 * (size_t)k * SBM;
+template <int NJ, int KS, int NCH, int WAVES, bool HALF2>
+static int launch_predict_topk_split_w(const float* A, const uint16_t* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
+                                       int k, int clamp, int32_t* out_idx, float* out_val, const float* item_scale, hipStream_t stream) {
+    constexpr int SBM = 32 * WAVES, SRING = split_ring(WAVES, HALF2), NP = HALF2 ? 2 : 3;
+    const size_t lds = (size_t)SRING * NP * (32 * NJ) * (32 * KS) + 3 * sizeof(float) * SBM + 8 * (size_t)split_cap(WAVES, k) * SBM +
+                       8 * (size_t)k * SBM;
     static LdsGrant grant;  // per template instance
-    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NJ, KS, NCH, WAVES>), lds, grant)) return rc;
+    if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NJ, KS, NCH, WAVES, HALF2>), lds, grant)) return rc;
     const int64_t blocks = (m + SBM - 1) / SBM;
     TMF_REQUIRE_LAUNCH(blocks, 64 * WAVES, "predict_topk_split");
-    hipLaunchKernelGGL((k_predict_topk_split<NJ, KS, NCH, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, A, Bp, m, n, n_pad, K, lda, k,
-                       clamp, out_idx, out_val);
-    return check_launch("tmf_predict_topk_split_f32");
+    hipLaunchKernelGGL((k_predict_topk_split<NJ, KS, NCH, WAVES, HALF2>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, A, Bp, m,
+                       n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale);
+    return check_launch(HALF2 ? "tmf_predict_topk_half2_f32" : "tmf_predict_topk_split_f32");
 }
 
 static int split_waves(int k) {   // TMF_SPLIT_WAVES=4|8 overrides (A/B runs)
@@ -418,16 +532,39 @@ static int split_waves(int k) {   // TMF_SPLIT_WAVES=4|8 overrides (A/B runs)
     return 4;
 }
 
-static int launch_predict_topk_split(int ldp, int k, const float* A, const __bf16* Bp, int64_t m, int64_t n, int64_t n_pad, int K,
-                                     int64_t lda, int clamp, int32_t* out_idx, float* out_val, hipStream_t s) {
+template <bool HALF2>
+static int launch_predict_topk_split(int ldp, int k, const float* A, const uint16_t* Bp, int64_t m, int64_t n, int64_t n_pad, int K,
+                                     int64_t lda, int clamp, int32_t* out_idx, float* out_val, const float* item_scale, hipStream_t s) {
     const bool w4 = split_waves(k) == 4;
-#define TMF_SPLIT_GO(NJ, KS, NCH)                                                                                              \
-    return w4 ? launch_predict_topk_split_w<NJ, KS, NCH, 4>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, s)         \
-              : launch_predict_topk_split_w<NJ, KS, NCH, 8>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, s)
-    if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
-    if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
-    TMF_SPLIT_GO(2, 4, 2);
+#define TMF_SPLIT_GO(NJ, KS, NCH)                                                                                                         \
+    return w4 ? launch_predict_topk_split_w<NJ, KS, NCH, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s)  \
+              : launch_predict_topk_split_w<NJ, KS, NCH, 8, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s)
+    if constexpr (HALF2) {   // 64 A registers at r = 128: 128-item tiles throughout, k-chunks of 32
+        if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
+        if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
+        TMF_SPLIT_GO(4, 2, 4);
+    } else {
+        if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
+        if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
+        TMF_SPLIT_GO(2, 4, 2);
+    }
 #undef TMF_SPLIT_GO
+}
+
+static int check_split_args(const char* what, const float* A, const float* B, int32_t* out_idx, int64_t m, int64_t n, int r,
+                            int64_t lda, int64_t ldb, int k, void* workspace, size_t workspace_bytes, size_t need) {
+    TMF_REQUIRE(A && B && out_idx && m > 0 && n > 0 && r > 0, "%s: bad arguments", what);
+    TMF_REQUIRE(lda >= r && ldb >= r && (lda % 4 == 0) && ((uintptr_t)A % 16 == 0),
+                "%s: the user table must be 16-byte aligned with ld %% 4 == 0", what);
+    TMF_REQUIRE(k >= 1 && k <= n, "%s: k=%d must be in [1, n=%lld]", what, k, (long long)n);
+    TMF_REQUIRE(n < ((int64_t)1 << 31), "%s: too many items", what);
+    if (!tmf_predict_topk_split_supported(r, k)) {
+        set_error("%s: supports k <= %d and n_components <= %d (got k=%d, r=%d)", what, SMAXK, SMAXR, k, r);
+        return TMF_E_UNSUPPORTED;
+    }
+    TMF_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
+                "%s: workspace of %zu bytes (16-byte aligned) needed, got %zu", what, need, workspace_bytes);
+    return TMF_OK;
 }
 
 }  // namespace tmf
@@ -438,25 +575,21 @@ extern "C" int tmf_predict_topk_split_supported(int r, int k) {
 
 extern "C" size_t tmf_predict_topk_split_workspace_bytes(int64_t n, int r) {
     if (n <= 0 || r < 1 || r > tmf::SMAXR) return 0;
-    return (size_t)3 * (size_t)tmf::split_rows_pad(n) * (size_t)tmf::split_ldp(r) * sizeof(__bf16);
+    return (size_t)3 * (size_t)tmf::split_rows_pad(n) * (size_t)tmf::split_ldp(r) * sizeof(uint16_t);
+}
+
+extern "C" size_t tmf_predict_topk_half2_workspace_bytes(int64_t n, int r) {
+    if (n <= 0 || r < 1 || r > tmf::SMAXR) return 0;
+    return (size_t)2 * (size_t)tmf::split_rows_pad(n) * (size_t)tmf::split_ldp(r) * sizeof(uint16_t) + 16;   // + max |V| and the scale
 }
 
 extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
                                           int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return TMF_OK;
-    TMF_REQUIRE(A && B && out_idx && m > 0 && n > 0 && r > 0, "predict_topk_split: bad arguments");
-    TMF_REQUIRE(lda >= r && ldb >= r && (lda % 4 == 0) && ((uintptr_t)A % 16 == 0),
-                "predict_topk_split: the user table must be 16-byte aligned with ld %% 4 == 0");
-    TMF_REQUIRE(k >= 1 && k <= n, "predict_topk_split: k=%d must be in [1, n=%lld]", k, (long long)n);
-    TMF_REQUIRE(n < ((int64_t)1 << 31), "predict_topk_split: too many items");
-    if (!tmf_predict_topk_split_supported(r, k)) {
-        tmf::set_error("predict_topk_split: supports k <= %d and n_components <= %d (got k=%d, r=%d)", tmf::SMAXK, tmf::SMAXR, k, r);
-        return TMF_E_UNSUPPORTED;
-    }
-    const size_t need = tmf_predict_topk_split_workspace_bytes(n, r);
-    TMF_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
-                "predict_topk_split: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, workspace_bytes);
+    if (int rc = tmf::check_split_args("predict_topk_split", A, B, out_idx, m, n, r, lda, ldb, k, workspace, workspace_bytes,
+                                       tmf_predict_topk_split_workspace_bytes(n, r)))
+        return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ldp = tmf::split_ldp(r);
     const int64_t n_pad = tmf::split_rows_pad(n);
@@ -467,5 +600,37 @@ extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_
         hipLaunchKernelGGL(tmf::k_split3_rows, dim3((unsigned)blocks), dim3(256), 0, s, B, n, r, ldb, Bp, n_pad, ldp);
         if (int rc = tmf::check_launch("tmf_predict_topk_split_f32 (item planes)")) return rc;
     }
-    return tmf::launch_predict_topk_split(ldp, k, A, Bp, m, n, n_pad, r, lda, clamp_negatives, out_idx, out_val, s);
+    return tmf::launch_predict_topk_split<false>(ldp, k, A, reinterpret_cast<const uint16_t*>(Bp), m, n, n_pad, r, lda, clamp_negatives,
+                                                 out_idx, out_val, nullptr, s);
+}
+
+extern "C" int tmf_predict_topk_half2_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
+                                          int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (m == 0) return TMF_OK;
+    if (int rc = tmf::check_split_args("predict_topk_half2", A, B, out_idx, m, n, r, lda, ldb, k, workspace, workspace_bytes,
+                                       tmf_predict_topk_half2_workspace_bytes(n, r)))
+        return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int ldp = tmf::split_ldp(r);
+    const int64_t n_pad = tmf::split_rows_pad(n);
+    _Float16* Bp = reinterpret_cast<_Float16*>(workspace);
+    char* tail = reinterpret_cast<char*>(workspace) + (size_t)2 * n_pad * ldp * sizeof(uint16_t);
+    unsigned* absmax = reinterpret_cast<unsigned*>(tail);
+    float* scale = reinterpret_cast<float*>(tail + 4);
+    if (hipMemsetAsync(absmax, 0, 8, s) != hipSuccess) { tmf::set_error("predict_topk_half2: hipMemsetAsync failed"); return TMF_E_LAUNCH; }
+    {
+        const int64_t total = n * (int64_t)r;
+        const unsigned blocks = (unsigned)(total / 4096 + 1 < 2048 ? total / 4096 + 1 : 2048);
+        hipLaunchKernelGGL(tmf::k_absmax, dim3(blocks), dim3(256), 0, s, B, n, r, ldb, absmax);
+        if (int rc = tmf::check_launch("tmf_predict_topk_half2_f32 (max)")) return rc;
+    }
+    {
+        const int64_t threads = n_pad * (ldp / 8), blocks = (threads + 255) / 256;
+        TMF_REQUIRE_LAUNCH(blocks, 256, "predict_topk_half2 (item planes)");
+        hipLaunchKernelGGL(tmf::k_split2_rows, dim3((unsigned)blocks), dim3(256), 0, s, B, n, r, ldb, Bp, n_pad, ldp, absmax, scale);
+        if (int rc = tmf::check_launch("tmf_predict_topk_half2_f32 (item planes)")) return rc;
+    }
+    return tmf::launch_predict_topk_split<true>(ldp, k, A, reinterpret_cast<const uint16_t*>(Bp), m, n, n_pad, r, lda, clamp_negatives,
+                                                out_idx, out_val, scale, s);
 }
