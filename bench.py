@@ -848,37 +848,43 @@ def main():
             _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True, arithmetic=arith)
             torch.cuda.synchronize()
             return time.perf_counter() - t1
-        # what the class surface runs at this size (arithmetic='auto'): for fp32 tables of width <= 128 the three-plane bf16 split
-        # (tmf_predict_topk_split_f32: fp32-accurate ranking on the bf16 matrix cores), else the fp32 / bf16 MFMA kernels
+        # what the class surface runs at this size (arithmetic='auto'): for fp32 tables of width <= 128 the ranking goes to the
+        # 16-bit matrix cores with fp32 accuracy - two fp16 planes per factor under power-of-two scales, three plane products
+        # (tmf_predict_topk_half2_f32), or three bf16 planes and six products when the item rows span more than 2^12 in
+        # magnitude (tmf_predict_topk_split_f32); else the fp32 / bf16 MFMA kernels
         dt = time_topk(None)
-        split_default = args.dtype != 'bf16' and _ops.split_topk_supported(wl.r, 10) and rows * wl.n >= _ops.SPLIT_MIN_SCORES
+        flops = 2.0 * rows * wl.n * wl.r
+        planes = args.dtype != 'bf16' and _ops.split_topk_supported(wl.r, 10) and rows * wl.n >= _ops.SPLIT_MIN_SCORES
+        chosen = ('half2' if _ops.half2_range_ok(Ve) else 'split') if planes else ('bf16' if args.dtype == 'bf16' else 'fp32')
         out['predict_rows_per_sec'] = rows / dt
-        out['predict_tflops'] = 2.0 * rows * wl.n * wl.r / dt / 1e12
+        out['predict_tflops'] = flops / dt / 1e12
+        out['predict_arithmetic'] = chosen
+        kernels = {'bf16': 'tmf_predict_topk_bf16 (bf16 tables: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)',
+                   'fp32': 'tmf_predict_topk_f32 (fp32 MFMA, peak 157.3 TF)',
+                   'split': 'tmf_predict_topk_split_f32 (fp32 tables split exactly into 3 bf16 planes, 6 plane products on v_mfma_f32_32x32x16_bf16, '
+                            'fp32 accumulate: fp32-accurate; predict_tflops is fp32-EQUIVALENT, the matrix-core work is 6x that; dense bf16 peak '
+                            '~2500 TF = 417 TF fp32-equivalent)',
+                   'half2': 'tmf_predict_topk_half2_f32 (fp32 tables as 2 fp16 planes under per-user-row / per-table power-of-two scales, 3 plane '
+                            'products on v_mfma_f32_32x32x16_f16, fp32 accumulate: 22 bits of every factor, values at the fp32 kernel\'s error; '
+                            'predict_tflops is fp32-EQUIVALENT, the matrix-core work is 3x that; dense fp16 peak ~2500 TF = 833 TF fp32-equivalent)'}
         out['predict_note'] = (f'stable top-10 of U.V^T over all {wl.n} items for {rows} users, fused MFMA GEMM + top-k, as '
-                               f'MatrixFactorization.retrieve_user_recs / recall_at_k run it: '
-                               + ('tmf_predict_topk_bf16 (bf16 tables: bf16 MFMA, fp32 accumulate; dense bf16 peak ~2500 TF)' if args.dtype == 'bf16'
-                                  else 'tmf_predict_topk_split_f32 (fp32 tables split exactly into 3 bf16 planes, 6 plane products on '
-                                       'v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-accurate; predict_tflops is fp32-EQUIVALENT, the bf16 MFMA work '
-                                       'is 6x that; dense bf16 peak ~2500 TF = 417 TF fp32-equivalent)' if split_default
-                                  else 'tmf_predict_topk_f32 (fp32 MFMA, peak 157.3 TF)'))
-        if args.dtype != 'bf16':
-            dt32 = time_topk('fp32') if split_default else dt
-            out['predict_fp32_mfma'] = dict(rows_per_sec=rows / dt32, tflops=2.0 * rows * wl.n * wl.r / dt32 / 1e12,
-                                            note='the same ranking by tmf_predict_topk_f32 (v_mfma_f32_32x32x2_f32, peak 157.3 TF): '
-                                                 "model.predict_arithmetic = 'fp32'")
-        if split_default:
+                               f'MatrixFactorization.retrieve_user_recs / recall_at_k run it: ' + kernels[chosen])
+        if planes:
             sample = min(rows, 2048)
             ref = (Ue[:sample].double() @ Ve.double().T).clamp_min(0)
             norm = float(ref.abs().max())
-            err = {}
-            for arith in ('fp32', 'split'):
+            by = {}
+            for arith, work in (('fp32', 1), ('split', 6), ('half2', 3)):
+                t = dt if arith == chosen else time_topk(arith)
                 v, i = _ops.predict_topk(Ue[:sample], Ve, 10, clamp_negatives=True, return_values=True, arithmetic=arith)
-                err[arith] = float((v.double() - torch.gather(ref, 1, i.long())).abs().max()) / max(norm, 1e-30)
+                by[arith] = dict(rows_per_sec=rows / t, tflops_fp32_equivalent=flops / t / 1e12, matrix_core_tflops=work * flops / t / 1e12,
+                                 max_abs_err_over_max_score_vs_fp64=float((v.double() - torch.gather(ref, 1, i.long())).abs().max()) / max(norm, 1e-30),
+                                 top10_rows_identical_to_fp64=float((i.long() == torch.topk(ref, 10, dim=1)[1]).all(1).float().mean()))
             del ref
-            out['predict_split'] = dict(rows_per_sec=rows / dt, tflops_fp32_equivalent=2.0 * rows * wl.n * wl.r / dt / 1e12,
-                                        bf16_mfma_tflops=12.0 * rows * wl.n * wl.r / dt / 1e12, over_fp32_kernel=dt32 / dt,
-                                        max_abs_err_over_max_score_vs_fp64=err, err_sample_users=sample,
-                                        note='errors of the returned top-10 values against an fp64 product, the fp32 MFMA kernel beside the split kernel')
+            out['predict_by_arithmetic'] = dict(by, err_sample_users=sample,
+                                                note="model.predict_arithmetic = 'fp32' | 'split' | 'half2' selects; errors of the returned "
+                                                     'top-10 values against an fp64 product of the same tables')
+            out['predict_fp32_mfma'] = dict(rows_per_sec=by['fp32']['rows_per_sec'], tflops=by['fp32']['tflops_fp32_equivalent'])
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want),
                                    case='C1 golden fixture: ranking of the oracle-trained tables (450 epochs)')

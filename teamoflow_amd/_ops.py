@@ -75,11 +75,27 @@ def split_topk_supported(r, k):
     return 1 <= r <= 128 and 1 <= k <= 32
 
 
+HALF2_MAX_ROW_RANGE = 2.0 ** 12   # largest / smallest item-row magnitude up to which 'auto' takes the two-plane fp16 kernel
+
+
+def half2_range_ok(item_rows):
+    """The fp16 planes of the item table share ONE power-of-two scale: rows whose largest magnitude is within 2^12 of the
+    table's keep 22 bits of their dominant factors (the second plane stays in fp16's normal range); beyond that the three
+    bf16 planes ('split': no range limit) are the safe choice.  One small reduction and a host read."""
+    row_max = item_rows.abs().amax(dim=1)
+    top = row_max.max()
+    low = torch.where(row_max > 0, row_max, top).min()
+    top, low = float(top), float(low)
+    return top == 0.0 or (top < float('inf') and low > 0 and top / low <= HALF2_MAX_ROW_RANGE)
+
+
 def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False, arithmetic=None):
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
-    fp32 tables: fp32 MFMA (k <= 64, width <= 256), or - arithmetic='split', width <= 128, k <= 32 - the fp32-accurate
-    three-plane bf16 split on the bf16 MFMA (tmf_predict_topk_split_f32: ~1.9x the rate, errors against fp64 at or below the fp32
-    kernel's); 'auto' takes the split kernel where it applies and the job has SPLIT_MIN_SCORES scores or more.
+    fp32 tables: fp32 MFMA (k <= 64, width <= 256), or - width <= 128, k <= 32 - on the 16-bit matrix cores with fp32 accuracy:
+    arithmetic='split' (three exact bf16 planes per factor, six products: ~1.9x the rate of the fp32 kernel, errors against fp64
+    at or below its) or 'half2' (two fp16 planes under power-of-two scales, three products: ~2.9x, errors at the fp32 kernel's;
+    one scale for the whole item table, hence half2_range_ok).  'auto' takes half2 - or split when the item rows span more than
+    2^12 in magnitude - where they apply and the job has SPLIT_MIN_SCORES scores or more.
     bf16 tables (both operands): bf16 MFMA with fp32 accumulation, k <= 32, width <= 256.
     See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
@@ -111,13 +127,15 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
     if arithmetic in ('split', 'half2') and not split_topk_supported(r, k):
         raise ValueError(f'the split kernels support widths <= 128 and k <= 32 (got {r}, {k})')
+    if arithmetic == 'auto' and m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k):
+        arithmetic = 'half2' if half2_range_ok(B[:, :r]) else 'split'
     if arithmetic == 'half2':
         need = lib.tmf_predict_topk_half2_workspace_bytes(n, r)
         ws = torch.empty(need, dtype=torch.uint8, device=A.device)
         _lib.check(lib.tmf_predict_topk_half2_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
                                                   _lib.ptr(idx), _lib.ptr(vals), _lib.ptr(ws), need, _lib.stream_ptr()), lib)
         return (vals, idx) if return_values else idx
-    if arithmetic == 'split' or (arithmetic == 'auto' and m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k)):
+    if arithmetic == 'split':
         need = lib.tmf_predict_topk_split_workspace_bytes(n, r)
         ws = torch.empty(need, dtype=torch.uint8, device=A.device)
         _lib.check(lib.tmf_predict_topk_split_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),

@@ -23,8 +23,9 @@ def expected(sc, k, clamp):
     return S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
 
 
+@pytest.mark.parametrize('arith', ['split', 'half2'])
 @pytest.mark.parametrize('seed', range(10))
-def test_exact_on_small_integer_factors(ops, seed):
+def test_exact_on_small_integer_factors(ops, seed, arith):
     """Small-integer factors: every plane product and every sum is exact, so the split kernel must return the oracle's
     ranking bit for bit - with exact score ties across tiles, clamping, ragged last tiles, every table width class
     (<= 32, <= 64, <= 128) and catalogs long enough for the warm-up pass (>= 256 tiles)."""
@@ -38,7 +39,7 @@ def test_exact_on_small_integer_factors(ops, seed):
     V = rng.integers(-span, span + 1, (n, r)).astype(np.float32)
     clamp = bool(rng.integers(0, 2))
     sc = U @ V.T
-    vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic='split')
+    vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic=arith)
     ref = expected(sc, k, clamp)
     assert np.array_equal(got.cpu().numpy(), ref), (m, n, r, k, clamp)
     assert np.array_equal(vals.cpu().numpy(), np.take_along_axis(np.where(sc > 0, sc, 0) if clamp else sc, ref, 1))
@@ -47,7 +48,8 @@ def test_exact_on_small_integer_factors(ops, seed):
 @pytest.mark.parametrize('m,n,r,k,clamp', [(700, 3000, 128, 10, False), (300, 129, 5, 3, False), (256, 128, 32, 32, True),
                                             (513, 5000, 64, 16, False), (300, 1000, 100, 10, True), (1024, 40000, 128, 10, False),
                                             (640, 33001, 64, 5, False), (333, 70000, 24, 1, False)])
-def test_values_are_fp32_accurate(ops, m, n, r, k, clamp):
+@pytest.mark.parametrize('arith', ['split', 'half2'])
+def test_values_are_fp32_accurate(ops, m, n, r, k, clamp, arith):
     """Gaussian factors at the scale of normalised tables: values against an fp64 product (tolerance 1e-6 of the largest score -
     the 1e-5 gate of the predictions with a decade to spare - and no worse than twice the fp32 MFMA kernel's own error), the
     ranking against the oracle's top_k of the fp64 scores wherever the k-th and (k+1)-th scores are further apart than that."""
@@ -60,8 +62,26 @@ def test_values_are_fp32_accurate(ops, m, n, r, k, clamp):
         ref = ref.clamp_min(0)
     norm = float(ref.abs().max())
     v32, i32 = ops.predict_topk(U, V, k, clamp_negatives=clamp, return_values=True, arithmetic='fp32')
-    vs, ix = ops.predict_topk(U, V, k, clamp_negatives=clamp, return_values=True, arithmetic='split')
+    if arith == 'half2':   # rows of very different magnitude: every user row has its own scale, the item table one
+        U = U * torch.exp2(torch.randint(-20, 20, (m, 1), generator=g).float())
+        V = V * torch.exp2(torch.randint(-5, 6, (n, 1), generator=g).float())
+        ref = U.double() @ V.double().T
+        if clamp:
+            ref = ref.clamp_min(0)
+        v32, i32 = ops.predict_topk(U, V, k, clamp_negatives=clamp, return_values=True, arithmetic='fp32')
+    vs, ix = ops.predict_topk(U, V, k, clamp_negatives=clamp, return_values=True, arithmetic=arith)
     vs, ix, v32, i32 = vs.cpu(), ix.cpu().long(), v32.cpu(), i32.cpu().long()
+    if arith == 'half2':   # judged row by row: a user's scores share the user's scale
+        norm = ref.abs().amax(1, keepdim=True).clamp_min(1e-300)
+        e32 = float(((v32.double() - torch.gather(ref, 1, i32)).abs() / norm).max())
+        es = float(((vs.double() - torch.gather(ref, 1, ix)).abs() / norm).max())
+        assert es < 1.5e-6 and es <= 2 * e32 + 2e-7, (es, e32)
+        kk = min(k + 1, n)
+        wv, wi = D.tf_top_k(ref, kk)
+        gaps = wv[:, :-1] - wv[:, 1:]
+        clear = (gaps.min(1).values > 6e-6 * norm[:, 0]) if gaps.numel() else torch.ones(m, dtype=torch.bool)
+        assert torch.equal(ix[clear], wi[clear, :k])
+        return
     e32 = float((v32.double() - torch.gather(ref, 1, i32)).abs().max()) / norm
     es = float((vs.double() - torch.gather(ref, 1, ix)).abs().max()) / norm
     assert es < 1e-6 and es <= 2 * e32 + 1e-7, (es, e32)
@@ -88,7 +108,28 @@ def test_split_is_exact_per_value(ops):
     assert np.array_equal(vals.cpu().numpy()[:, 0], xs) and int(idx.abs().max()) == 0
 
 
-def test_deferred_merges_and_overflow(ops):
+def test_half2_keeps_22_bits_per_value(ops):
+    """One user per value x, one item [1.0]: two fp16 planes under the row's power-of-two scale give x back to 22 bits."""
+    rng = np.random.default_rng(4)
+    xs = (rng.standard_normal(4000) * np.exp(rng.uniform(-30, 30, 4000))).astype(np.float32)
+    xs = np.concatenate([np.array([0.0, 1.0, -1.0, 0.1, 3.14159274, 65504.0, 1e-20, -7.7e-12, 123456.789], dtype=np.float32), xs])
+    vals, _ = ops.predict_topk(torch.tensor(xs[:, None].copy()), torch.ones(1, 1), 1, return_values=True, arithmetic='half2')
+    got = vals.cpu().numpy()[:, 0]
+    assert np.all(np.abs(got - xs) <= 2.0 ** -21 * np.abs(xs))
+
+
+def test_half2_range_guard(ops):
+    """'auto' takes the fp16 planes only while the item rows span <= 2^12 in magnitude (one scale for the whole table)."""
+    V = torch.randn(1000, 16)
+    assert ops.half2_range_ok(V.cuda())
+    V[3] *= 1e6
+    assert not ops.half2_range_ok(V.cuda())
+    V[3] = 0
+    assert ops.half2_range_ok(V.cuda()) and ops.half2_range_ok(torch.zeros(4, 4, device='cuda'))
+
+
+@pytest.mark.parametrize('arith', ['split', 'half2'])
+def test_deferred_merges_and_overflow(ops, arith):
     """Records every 20..41 items (pending buffers fill over several tiles, rows merge at different times, the last records sit
     in the last tiles), and scores increasing with the item index (every tile overflows the pending buffer)."""
     n, r, m = 3001, 8, 300
@@ -100,16 +141,16 @@ def test_deferred_merges_and_overflow(ops):
     sc = U @ V.T
     for k in (1, 10, 32):
         for clamp in (False, True):
-            vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic='split')
+            vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic=arith)
             ref = expected(sc, k, clamp)
             assert np.array_equal(got.cpu().numpy(), ref), (k, clamp)
     inc = torch.arange(40000, dtype=torch.float32)[:, None] * torch.ones(1, 4)      # long enough for the warm-up pass
-    got = ops.predict_topk(torch.ones(7, 4), inc, 5, arithmetic='split').cpu().tolist()
+    got = ops.predict_topk(torch.ones(7, 4), inc, 5, arithmetic=arith).cpu().tolist()
     assert got == [[39999, 39998, 39997, 39996, 39995]] * 7
     Z = torch.zeros(200, 16)                                                         # everything clamped to 0: 0..k-1
-    assert ops.predict_topk(Z, torch.ones(40000, 16), 10, clamp_negatives=True, arithmetic='split').cpu().tolist() == [list(range(10))] * 200
+    assert ops.predict_topk(Z, torch.ones(40000, 16), 10, clamp_negatives=True, arithmetic=arith).cpu().tolist() == [list(range(10))] * 200
     dec = -inc                                                                       # best items first: the warm-up bound is tight
-    assert ops.predict_topk(torch.ones(3, 4), dec, 4, arithmetic='split').cpu().tolist() == [[0, 1, 2, 3]] * 3
+    assert ops.predict_topk(torch.ones(3, 4), dec, 4, arithmetic=arith).cpu().tolist() == [[0, 1, 2, 3]] * 3
 
 
 def test_limits_and_errors(ops):
