@@ -329,7 +329,8 @@ int tmf_predict_topk_split_f32(const float* A, const float* B, int64_t m, int64_
  * user row is scaled by its own power of two and the item table by one, so that the planes sit in fp16's normal range; 22
  * bits of every factor take part (all 24 with the three bf16 planes above), and a factor below ~1e-6 of its table's largest
  * magnitude keeps fewer.  Values against fp64: at the fp32 MFMA kernel's error (csrc/tmf_predict_split.hip, tests).  Half the
- * matrix-core work of the three-plane form.  Same limits (tmf_predict_topk_split_supported); its own workspace size. */
+ * matrix-core work of the three-plane form.  r <= 256, k <= 32 (tmf_predict_topk_half2_supported); its own workspace size. */
+int tmf_predict_topk_half2_supported(int r, int k);
 size_t tmf_predict_topk_half2_workspace_bytes(int64_t n, int r);
 int tmf_predict_topk_half2_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,
                                int64_t ldb, int k, int clamp_negatives, int32_t* out_idx, float* out_val,

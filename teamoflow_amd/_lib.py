@@ -100,6 +100,7 @@ _BASE_SIGNATURES = {
     'tmf_predict_topk_split_supported': (_I, [_I, _I]),
     'tmf_predict_topk_split_workspace_bytes': (_SZ, [_L, _I]),
     'tmf_predict_topk_split_f32': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P, _SZ, _P]),
+    'tmf_predict_topk_half2_supported': (_I, [_I, _I]),
     'tmf_predict_topk_half2_workspace_bytes': (_SZ, [_L, _I]),
     'tmf_predict_topk_half2_f32': (_I, [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P, _P, _P, _SZ, _P]),
 }

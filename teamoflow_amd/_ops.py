@@ -75,6 +75,10 @@ def split_topk_supported(r, k):
     return 1 <= r <= 128 and 1 <= k <= 32
 
 
+def half2_topk_supported(r, k):
+    return 1 <= r <= 256 and 1 <= k <= 32
+
+
 HALF2_MAX_ROW_RANGE = 2.0 ** 12   # largest / smallest item-row magnitude up to which 'auto' takes the two-plane fp16 kernel
 
 
@@ -125,10 +129,13 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
         raise ValueError(f'k={k} must be in [1, {n}]')
     idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
-    if arithmetic in ('split', 'half2') and not split_topk_supported(r, k):
-        raise ValueError(f'the split kernels support widths <= 128 and k <= 32 (got {r}, {k})')
-    if arithmetic == 'auto' and m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k):
-        arithmetic = 'half2' if half2_range_ok(B[:, :r]) else 'split'
+    if (arithmetic == 'split' and not split_topk_supported(r, k)) or (arithmetic == 'half2' and not half2_topk_supported(r, k)):
+        raise ValueError(f'the split kernels support widths <= 128 (half2: 256) and k <= 32 (got {r}, {k})')
+    if arithmetic == 'auto' and m * n >= SPLIT_MIN_SCORES and half2_topk_supported(r, k):
+        if half2_range_ok(B[:, :r]):
+            arithmetic = 'half2'
+        elif split_topk_supported(r, k):
+            arithmetic = 'split'
     if arithmetic == 'half2':
         need = lib.tmf_predict_topk_half2_workspace_bytes(n, r)
         ws = torch.empty(need, dtype=torch.uint8, device=A.device)

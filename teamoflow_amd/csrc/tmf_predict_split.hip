@@ -19,6 +19,13 @@
 // (per-row threshold in registers, pending buffer, one lane per row merges) but without LDS atomics, and a warm-up pass over
 // the first 1/64 of the catalog gives every row a threshold to start from.
 //
+// The HALF2 form of the same kernel (tmf_predict_topk_half2_f32) takes two fp16 planes per factor and three products
+// (h2 v1 + h1 v2 + h1 v1 on v_mfma_f32_32x32x16_f16): fp16 has 11 significant bits, so two planes carry 22 bits of a factor once
+// a power-of-two scale has put them into fp16's normal range - one scale per user row (found while the row is loaded), one for
+// the item table (a max reduction before the split).  A row's scores all carry the same factor, which the ranking ignores
+// and the epilogue takes out of the values.  Half the matrix-core work, 64 instead of 96 A registers at r = 128 (r <= 256
+// fits), values against fp64 at the fp32 MFMA kernel's error: 19.9 ms = 338 TF fp32-equivalent at r = 128 (item 7 of the notes).
+//
 // Measured (262144 x 100000, k = 10, random factors; tools/split_time.py, profiles/r03_predict_split.txt): r = 128: 29.9 ms =
 // 224.7 TF fp32-equivalent = 1.35 PFLOP/s of bf16 MFMA work (fp32 MFMA kernel: 57 ms, 118 TF); r = 64: 195 TF; r = 32: 149 TF.
 // Timing-only variants of the r = 128 run: without the candidate handling 27.3 ms, also without the chunk barrier 28.4 (no
@@ -41,7 +48,7 @@ typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_s;
 typedef __attribute__((address_space(1))) const void gbl_void_s;
 
-constexpr int SMAXK = 32, SMAXR = 128;
+constexpr int SMAXK = 32, SMAXR = 128, SMAXR_HALF2 = 256;
 // Two shapes of workgroup.  WAVES = 4 (128 users, 2-slot ring, two workgroups per CU, k <= 16): the workgroups of a CU drift
 // apart, so one multiplies while the other stands at its chunk barrier or files candidates - the two waves of a SIMD no longer
 // stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop, for k > 16
@@ -212,55 +219,59 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     {
         const int64_t r = row0 + 32 * wave + l31;
         const float* p = A + (r < m ? r : 0) * lda;
-        float x[NK][8];
+        auto load8 = [&](int kk, float (&x)[8]) {   // this lane's eight factors of k-step kk (zeros past K and past the last row)
 #pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[kk][e] = 0.f;
+            for (int e = 0; e < 8; ++e) x[e] = 0.f;
             const int k0 = 16 * kk + 8 * h;
             if (r < m && k0 < K) {
                 if (k0 + 7 < K) {
                     const f32x4_s lo = *reinterpret_cast<const f32x4_s*>(p + k0), hi = *reinterpret_cast<const f32x4_s*>(p + k0 + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[kk][e] = lo[e]; x[kk][4 + e] = hi[e]; }
+                    for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
                 } else {
-                    for (int e = 0; e < 8; ++e) if (k0 + e < K) x[kk][e] = p[k0 + e];
+                    for (int e = 0; e < 8; ++e) if (k0 + e < K) x[e] = p[k0 + e];
                 }
             }
-        }
+        };
+        float sc = 1.f;
         if constexpr (HALF2) {
-            float mx = 0.f;   // the row's largest finite magnitude: this lane's half of the k-slices, then the other half's
-#pragma unroll
-            for (int kk = 0; kk < NK; ++kk)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = fabsf(x[kk][e]);
-                    mx = (v > mx && __builtin_isfinite(v)) ? v : mx;
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float sc = half_scale_for(mx);
-            if (h == 0) inv_scale[32 * wave + l31] = 1.f / (sc * *item_scale);   // both powers of two: exact
+            float mx = 0.f;   // the row's largest finite magnitude (the row is read twice: once for this, once for the planes)
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
+                float x[8];
+                load8(kk, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = fabsf(x[e]);
+                    mx = (v > mx && __builtin_isfinite(v)) ? v : mx;
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));   // the other half of the k-slices
+            sc = half_scale_for(mx);
+            if (h == 0) inv_scale[32 * wave + l31] = 1.f / (sc * *item_scale);   // both powers of two: exact
+        } else {
+            if (h == 0) inv_scale[32 * wave + l31] = 1.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            float x[8];
+            load8(kk, x);
+            if constexpr (HALF2) {
                 f16x8_s p1, p2;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     _Float16 u, v;
-                    split2h(x[kk][e], sc, u, v);
+                    split2h(x[e], sc, u, v);
                     p1[e] = u; p2[e] = v;
                 }
                 a[0][kk] = __builtin_bit_cast(raw16_s, p1);
                 a[1][kk] = __builtin_bit_cast(raw16_s, p2);
-            }
-        } else {
-            if (h == 0) inv_scale[32 * wave + l31] = 1.f;
-#pragma unroll
-            for (int kk = 0; kk < NK; ++kk) {
+            } else {
                 bf16x8_s p1, p2, p3;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     __bf16 u, v, w;
-                    split3(x[kk][e], u, v, w);
+                    split3(x[e], u, v, w);
                     p1[e] = u; p2[e] = v; p3[e] = w;
                 }
                 a[0][kk] = __builtin_bit_cast(raw16_s, p1);
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
 }
 
 static int64_t split_rows_pad(int64_t n) { return (n + kSplitRowsPad - 1) / kSplitRowsPad * kSplitRowsPad; }
-static int split_ldp(int r) { return r <= 32 ? 32 : r <= 64 ? 64 : 128; }
+static int split_ldp(int r) { return r <= 32 ? 32 : r <= 64 ? 64 : r <= 128 ? 128 : 256; }
 
 template <int NJ, int KS, int NCH, int WAVES, bool HALF2>
 static int launch_predict_topk_split_w(const float* A, const uint16_t* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
@@ -542,7 +553,8 @@ static int launch_predict_topk_split(int ldp, int k, const float* A, const uint1
     if constexpr (HALF2) {   // 64 A registers at r = 128: 128-item tiles throughout, k-chunks of 32
         if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
         if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
-        TMF_SPLIT_GO(4, 2, 4);
+        if (ldp == 128) { TMF_SPLIT_GO(4, 2, 4); }
+        TMF_SPLIT_GO(2, 4, 4);   // r <= 256: 128 A registers, 64-item tiles
     } else {
         if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
         if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
@@ -552,14 +564,14 @@ static int launch_predict_topk_split(int ldp, int k, const float* A, const uint1
 }
 
 static int check_split_args(const char* what, const float* A, const float* B, int32_t* out_idx, int64_t m, int64_t n, int r,
-                            int64_t lda, int64_t ldb, int k, void* workspace, size_t workspace_bytes, size_t need) {
+                            int64_t lda, int64_t ldb, int k, void* workspace, size_t workspace_bytes, size_t need, int max_r) {
     TMF_REQUIRE(A && B && out_idx && m > 0 && n > 0 && r > 0, "%s: bad arguments", what);
     TMF_REQUIRE(lda >= r && ldb >= r && (lda % 4 == 0) && ((uintptr_t)A % 16 == 0),
                 "%s: the user table must be 16-byte aligned with ld %% 4 == 0", what);
     TMF_REQUIRE(k >= 1 && k <= n, "%s: k=%d must be in [1, n=%lld]", what, k, (long long)n);
     TMF_REQUIRE(n < ((int64_t)1 << 31), "%s: too many items", what);
-    if (!tmf_predict_topk_split_supported(r, k)) {
-        set_error("%s: supports k <= %d and n_components <= %d (got k=%d, r=%d)", what, SMAXK, SMAXR, k, r);
+    if (r > max_r || k > SMAXK) {
+        set_error("%s: supports k <= %d and n_components <= %d (got k=%d, r=%d)", what, SMAXK, max_r, k, r);
         return TMF_E_UNSUPPORTED;
     }
     TMF_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
@@ -578,8 +590,12 @@ extern "C" size_t tmf_predict_topk_split_workspace_bytes(int64_t n, int r) {
     return (size_t)3 * (size_t)tmf::split_rows_pad(n) * (size_t)tmf::split_ldp(r) * sizeof(uint16_t);
 }
 
+extern "C" int tmf_predict_topk_half2_supported(int r, int k) {
+    return r >= 1 && r <= tmf::SMAXR_HALF2 && k >= 1 && k <= tmf::SMAXK;
+}
+
 extern "C" size_t tmf_predict_topk_half2_workspace_bytes(int64_t n, int r) {
-    if (n <= 0 || r < 1 || r > tmf::SMAXR) return 0;
+    if (n <= 0 || r < 1 || r > tmf::SMAXR_HALF2) return 0;
     return (size_t)2 * (size_t)tmf::split_rows_pad(n) * (size_t)tmf::split_ldp(r) * sizeof(uint16_t) + 16;   // + max |V| and the scale
 }
 
@@ -588,7 +604,7 @@ extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return TMF_OK;
     if (int rc = tmf::check_split_args("predict_topk_split", A, B, out_idx, m, n, r, lda, ldb, k, workspace, workspace_bytes,
-                                       tmf_predict_topk_split_workspace_bytes(n, r)))
+                                       tmf_predict_topk_split_workspace_bytes(n, r), tmf::SMAXR))
         return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ldp = tmf::split_ldp(r);
@@ -609,7 +625,7 @@ extern "C" int tmf_predict_topk_half2_f32(const float* A, const float* B, int64_
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return TMF_OK;
     if (int rc = tmf::check_split_args("predict_topk_half2", A, B, out_idx, m, n, r, lda, ldb, k, workspace, workspace_bytes,
-                                       tmf_predict_topk_half2_workspace_bytes(n, r)))
+                                       tmf_predict_topk_half2_workspace_bytes(n, r), tmf::SMAXR_HALF2))
         return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ldp = tmf::split_ldp(r);

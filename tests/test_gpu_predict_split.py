@@ -118,6 +118,30 @@ def test_half2_keeps_22_bits_per_value(ops):
     assert np.all(np.abs(got - xs) <= 2.0 ** -21 * np.abs(xs))
 
 
+@pytest.mark.parametrize('r', [129, 200, 256])
+def test_half2_wide_tables(ops, r):
+    """The fp16 form reaches width 256 (128 A registers per lane): exact on integer factors, fp32-accurate on Gaussian ones."""
+    rng = np.random.default_rng(r)
+    m, n, k = 300, 33001, 10
+    U = rng.integers(-2, 3, (m, r)).astype(np.float32)
+    V = rng.integers(-2, 3, (n, r)).astype(np.float32)
+    sc = U @ V.T
+    vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, return_values=True, arithmetic='half2')
+    ref = expected(sc, k, False)
+    assert np.array_equal(got.cpu().numpy(), ref) and np.array_equal(vals.cpu().numpy(), np.take_along_axis(sc, ref, 1))
+    g = torch.Generator().manual_seed(r)
+    Ug, Vg = torch.randn(m, r, generator=g) * 0.05, torch.randn(n, r, generator=g) * 0.05
+    want = Ug.double() @ Vg.double().T
+    vh, ih = ops.predict_topk(Ug, Vg, k, return_values=True, arithmetic='half2')
+    v32, i32 = ops.predict_topk(Ug, Vg, k, return_values=True, arithmetic='fp32')
+    norm = float(want.abs().max())
+    eh = float((vh.cpu().double() - torch.gather(want, 1, ih.cpu().long())).abs().max()) / norm
+    e32 = float((v32.cpu().double() - torch.gather(want, 1, i32.cpu().long())).abs().max()) / norm
+    assert eh < 1.5e-6 and eh <= 2 * e32 + 2e-7, (eh, e32)
+    lib = __import__('teamoflow_amd._lib', fromlist=['get']).get()
+    assert lib.tmf_predict_topk_half2_supported(256, 32) == 1 and lib.tmf_predict_topk_half2_supported(257, 1) == 0
+
+
 def test_half2_range_guard(ops):
     """'auto' takes the fp16 planes only while the item rows span <= 2^12 in magnitude (one scale for the whole table)."""
     V = torch.randn(1000, 16)
