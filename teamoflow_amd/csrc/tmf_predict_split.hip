@@ -198,7 +198,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     constexpr int LDP = 16 * KS * NCH, SBN = 32 * NJ, SROW = 32 * KS /* bytes, unpadded: the image is written by LDS-DMA */, SPLANE = SBN * SROW, SSLOT = NP * SPLANE;
     constexpr int NK = KS * NCH;   // k-steps per plane
     constexpr int SBM = 32 * WAVES, THREADS = 64 * WAVES, SRING = split_ring(WAVES, HALF2);
-    constexpr int LPW = 8 / WAVES;   // LDS-DMA loads per plane, chunk and wave
+    constexpr int LPW = NJ * KS / WAVES;   // LDS-DMA loads per plane, chunk and wave (a plane of a chunk is NJ KS pieces of 1 KB)
+    static_assert(LPW * WAVES == NJ * KS, "the waves share the pieces of a plane evenly");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* Bs = smem_raw;                                               // [SRING slots][3 planes][SBN][SROW] bytes
     float* tau = reinterpret_cast<float*>(Bs + SRING * SSLOT);         // [SBM]
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     // row's piece q ^ swz(i), swz(i) = (i / (16 / SR)) % SR, which spreads the pieces that 16 consecutive rows read together
     // over all 16 bank slots; the operand reads apply the same XOR.
     constexpr int SR = 2 * KS, RW = 64 / SR;
-    static_assert(8 * RW == SBN, "eight wave-instructions fill one plane of a tile");
+    static_assert(RW * NJ * KS == SBN, "NJ KS wave-instructions fill one plane of a tile");
     int s_off[LPW];   // element offset of this lane's source piece in row group i of the wave (rows RW LPW wave + RW i + lane / SR)
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
