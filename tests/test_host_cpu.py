@@ -243,3 +243,21 @@ def test_item_slices_and_defaults_on_cpu(monkeypatch):
     assert _engine.default_user_chunks(1_250_000, 256, n_items=1_000_000) == 8   # an 8 GB slab budget bounds it
     monkeypatch.setenv('TMF_SLAB_BUDGET', str(64 << 30))
     assert _engine.default_user_chunks(1_250_000, 256, n_items=1_000_000) == 67
+
+
+def test_half2_range_guard_on_cpu():
+    """The 'auto' rule of the fused top-k takes the two-plane fp16 kernel only while the item rows span <= 2^12 in magnitude
+    (one power-of-two scale for the whole item table); pure tensor logic, no GPU needed."""
+    import torch
+    from teamoflow_amd import _ops
+    g = torch.Generator().manual_seed(0)
+    V = torch.randn(500, 8, generator=g)
+    assert _ops.half2_range_ok(V) and _ops.half2_range_ok(torch.zeros(3, 4))
+    V[7] *= 2.0 ** 14
+    assert not _ops.half2_range_ok(V)
+    V[7] = 0                                   # all-zero rows do not count
+    assert _ops.half2_range_ok(V)
+    V[9, 0] = float('inf')
+    assert not _ops.half2_range_ok(V)
+    assert _ops.split_topk_supported(128, 32) and not _ops.split_topk_supported(129, 1)
+    assert _ops.half2_topk_supported(256, 32) and not _ops.half2_topk_supported(257, 1) and not _ops.half2_topk_supported(8, 33)
