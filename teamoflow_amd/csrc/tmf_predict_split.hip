@@ -49,10 +49,10 @@ typedef __attribute__((address_space(3))) void lds_void_s;
 typedef __attribute__((address_space(1))) const void gbl_void_s;
 
 constexpr int SMAXK = 32, SMAXR = 128, SMAXR_HALF2 = 256;
-// Two shapes of workgroup.  WAVES = 4 (128 users, 2-slot ring, two workgroups per CU, k <= 16): the workgroups of a CU drift
+// Two shapes of workgroup.  WAVES = 4 (128 users, two workgroups per CU, k <= 22): the workgroups of a CU drift
 // apart, so one multiplies while the other stands at its chunk barrier or files candidates - the two waves of a SIMD no longer
-// stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop, for k > 16
-// where two sets of lists do not fit the LDS.  Pending entries per row: what the LDS leaves next to the lists.
+// stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop, for k > 22
+// where two sets of lists do not fit the LDS (k > 22).  Pending entries per row: what the LDS leaves next to the lists.
 __host__ __device__ constexpr int split_cap(int waves, int k) { return waves == 4 ? (k <= 12 ? 16 : 8) : (k <= 16 ? 16 : 8); }
 // LDS ring slots: the two-plane chunks of the fp16 form are small enough for three of them beside two workgroups' lists
 __host__ __device__ constexpr int split_ring(int waves, bool half2) { return (waves == 4 && !half2) ? 2 : 3; }
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     // bound of the row's final k-th value.  The scan then restarts at tile 0 with every threshold just below that bound:
     // the rows skip the phase in which nearly every score is a candidate (half of all k (1 + ln(n / k)) insertions of a row
     // fall into its first ~5 tiles) for warm / ntiles (<= 1/64) more MFMA work.
-    const int warm = (k <= 16 && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
+    const int warm = (k <= 24 && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
     const int warm_chunks = warm * NCH;
     const int64_t plane = n_pad * LDP;
     auto g_issue = [&](int g, int slot) {   // chunk g -> ring slot `slot` (three LDS-DMA loads per wave)
@@ -540,7 +540,7 @@ static int launch_predict_topk_split_w(const float* A, const uint16_t* Bp, int64
 
 static int split_waves(int k) {   // TMF_SPLIT_WAVES=4|8 overrides (A/B runs)
     static const int forced = [] { const char* e = getenv("TMF_SPLIT_WAVES"); return e ? atoi(e) : 0; }();
-    if (forced == 8 || k > 16) return 8;
+    if (forced == 8 || k > 22) return 8;   // k <= 22: two workgroups' lists still fit beside their rings (80 KB each)
     return 4;
 }
 
