@@ -66,6 +66,12 @@ __device__ __forceinline__ float max_raw(float a, float b) {
     return r;
 }
 
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ bool before_s(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
 // x -> (x1, x2, x3) with x1 + x2 + x3 == x exactly for every finite x whose residuals stay normal.  A value that rounds to
@@ -354,18 +360,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     } else {
         load_tau();
     }
+    // Which of this wave's sixteen accumulator registers (row pairs) hold a score above its row's threshold in some lane: two
+    // three-input maxima and one compare per register, the verdicts collected in a scalar mask (the lanes that pass are found
+    // again by offer(), which compares every score of such a register anyway).
+    const float floor_v = clamp ? 0.f : -INFINITY;
     auto prefilter = [&]() -> unsigned {
-        unsigned pass = 0;
+        unsigned qmask = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            float mx = acc[0][q];
-#pragma unroll
-            for (int j = 1; j < NJ; ++j) mx = max_raw(mx, acc[j][q]);
-            if (clamp) mx = max_raw(mx, 0.f);
-            pass |= (mx > tq[q]) ? (1u << q) : 0u;
+            float mx;
+            if constexpr (NJ == 4) mx = max3_raw(max3_raw(acc[0][q], acc[1][q], acc[2][q]), acc[3][q], floor_v);
+            else mx = max3_raw(acc[0][q], acc[1][q], floor_v);
+            qmask |= (__ballot(mx > tq[q]) != 0) ? (1u << q) : 0u;
         }
-        return pass;
+        return qmask;
     };
+    static_assert(NJ == 2 || NJ == 4, "prefilter is written for two or four column blocks");
     const int n32 = (int)n;
     // Appending candidates takes no LDS atomic (hipcc drains the LDS-DMA queue, vmcnt(0), before every LDS atomic): the lanes
     // of a half-wave that hold candidates of one row take consecutive slots by ballot + popcount behind the row's count, which
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
         }
         const int col0 = tile * SBN;
         const unsigned pass = prefilter();
-        if (__any(pass != 0u)) {  // candidates are appended; lists and thresholds catch up when a buffer is half full
+        if (pass != 0u) {  // (wave-uniform) candidates are appended; lists and thresholds catch up when a buffer is half full
             offer(col0, -1, pass);
             const int my_row = 32 * wave + l31;
             const int c_now = (h == 0) ? cnt[my_row] : 0;
