@@ -213,3 +213,36 @@ def test_model_level_switch(ops):
     model.predict_arithmetic = 'split'
     b = model.retrieve_user_recs(k=10)
     assert a.dtype == np.int32 and (a == b).all(1).mean() > 0.999
+
+
+def test_auto_rule_at_catalog_scale(ops, monkeypatch):
+    """arithmetic='auto' from 2^26 scores on: the fp16 planes while the item rows span <= 2^12 in magnitude, the bf16 planes beyond
+    (one item row a million times larger than the rest) - either way the fp64 ranking on rows with clear gaps, and the explicit
+    'half2' call on the wide-range table still inside the norm-wise bound."""
+    g = torch.Generator().manual_seed(77)
+    m, n, r, k = 2048, 33000, 64, 10
+    assert m * n >= ops.SPLIT_MIN_SCORES
+    U = (torch.randn(m, r, generator=g) * 0.05).cuda()
+    V = (torch.randn(n, r, generator=g) * 0.05).cuda()
+    for big_row in (False, True):
+        if big_row:
+            V = V.clone()
+            V[123] *= 1e6
+        assert ops.half2_range_ok(V) == (not big_row)
+        ref = U.double() @ V.double().T
+        wv, wi = torch.topk(ref, k + 1, dim=1)
+        vals, idx = ops.predict_topk(U, V, k, return_values=True)            # auto
+        norm = ref.abs().amax(1, keepdim=True)
+        # gaps judged against the scores' own size: the kernel 'auto' picked resolves every factor to fp32 precision, so the
+        # ranking among ordinary items holds even beside an item whose scores are a million times larger
+        scale = wv[:, 1:].abs().amax(1)
+        clear = ((wv[:, :-1] - wv[:, 1:]).min(1).values > 2e-5 * scale)
+        assert clear.float().mean() > 0.5
+        assert torch.equal(idx.long()[clear], wi[clear, :k])
+        got = torch.gather(ref, 1, idx.long())
+        ordinary = (idx.long() != 123) if big_row else torch.ones_like(idx, dtype=torch.bool)   # the big item's scores: norm-wise, below
+        err = (((vals.double() - got).abs() / scale[:, None]) * ordinary).max()
+        assert float(err) < 2e-6
+        vh, ih = ops.predict_topk(U, V, k, return_values=True, arithmetic='half2')
+        errh = (vh.double() - torch.gather(ref, 1, ih.long())).abs().max() / ref.abs().max()
+        assert float(errh) < 2e-6
