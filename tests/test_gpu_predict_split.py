@@ -3,6 +3,7 @@ contract as the fp32 MFMA kernel - tf.math.top_k order (value desc, index asc), 
 CPU oracle (oracle/sparse_ref.topk_stable, oracle/dense_ref.tf_top_k) and an fp64 product.  Reference semantics:
 matrix_factorization.py:236-248 (recall_at_k) and :424-438 (retrieve_user_recs): tf.math.top_k(U V^T, k)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -24,7 +25,7 @@ def expected(sc, k, clamp):
 
 
 @pytest.mark.parametrize('arith', ['split', 'half2'])
-@pytest.mark.parametrize('seed', range(10))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('TMF_FUZZ_SEEDS', '10'))))
 def test_exact_on_small_integer_factors(ops, seed, arith):
     """Small-integer factors: every plane product and every sum is exact, so the split kernel must return the oracle's
     ranking bit for bit - with exact score ties across tiles, clamping, ragged last tiles, every table width class
