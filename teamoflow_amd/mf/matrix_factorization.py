@@ -379,7 +379,9 @@ class MatrixFactorization:
             nz = A.values != 0
             # column first, mask second: masked ROW selection of a [nnz, 2] tensor is unreliable beyond ~6e7 rows on this
             # PyTorch-ROCm build (tools/torch_row_index_probe.py)
-            keys = torch.sort(A.indices[:, 0][nz] * n + A.indices[:, 1][nz])[0]
+            keys = A.indices[:, 0][nz] * n + A.indices[:, 1][nz]
+            if keys.numel() > 1 and not bool((keys[1:] >= keys[:-1]).all()):   # row-major input (the reference's format) is sorted already
+                keys = torch.sort(keys)[0]
             q = torch.arange(m, device=top.device)[:, None] * n + top.to(torch.int64)
             pos = torch.clamp(torch.searchsorted(keys, q.reshape(-1)), max=max(keys.numel() - 1, 0))
             found = (keys[pos] == q.reshape(-1)).reshape(q.shape) if keys.numel() else torch.zeros_like(q, dtype=torch.bool)
