@@ -36,42 +36,97 @@ from teamoflow_amd.mf.utils import random_sampler_device  # noqa: E402
 HBM_PEAK, L2_PEAK, MALL_BYTES = 8.0e12, 34.5e12, 256 << 20
 L2_GATHER_MEASURED = (16.8e12, 18.8e12)  # the guide's measured chip-wide rate of L2-resident row gathers
 HBM_COPY_MEASURED = 6.29e12                # the guide's measured float4 copy from HBM (79 % of the 8 TB/s spec)
+FABRIC_GATHER_MEASURED = 8.6e12            # the guide's measured rate of row gathers served by the Infinity Cache (38 MB table)
 FABRIC_BOUND_FROM = 0.75                   # measured fabric traffic from this share of the HBM peak on = the kernel is bound there
+FABRIC_LABEL = 'fabric (L2-miss traffic incl. Infinity-Cache hits)'
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def gen_interactions(m, n, nnz_target, items, seed, dev):
+GEN_CHUNK_DRAWS = 1 << 25     # item draws generated at a time (bounds the transient memory of the generator: ~2 GB)
+CALIBRATION_USERS = 65536     # users 0 .. 65535 of the problem calibrate the duplicate rate of the item draws (every rank draws them)
+
+
+def drawn_degrees(m, n, nnz_target, seed, dev, inflate=1.0):
+    """Item draws per user of the WHOLE problem (int64 [m]): lognormal(4.2, 0.8) weights - Box-Muller on two counter_hash words
+    of (seed, user) - rescaled so that the draws sum to nnz_target * inflate.  O(m) work, the same vector on every rank."""
+    from teamoflow_amd.mf.utils import counter_hash, hash_unit
+    u = torch.arange(m, device=dev, dtype=torch.int64)
+    z = torch.sqrt(-2.0 * torch.log(hash_unit(counter_hash(seed, u, 1)))) * torch.cos(2.0 * np.pi * hash_unit(counter_hash(seed, u, 2)))
+    w = torch.exp(4.2 + 0.8 * z)
+    return torch.clamp(torch.round(w * (nnz_target * inflate / float(w.sum()))), 1, max(1, n // 4)).to(torch.int64)
+
+
+def item_permutation(n, dev):
+    """The fixed permutation the power-law ranks are mapped through (the popular items are spread over the id range)."""
+    from teamoflow_amd.mf.utils import _srl, counter_hash
+    return torch.argsort(_srl(counter_hash(4242, torch.arange(n, device=dev, dtype=torch.int64)), 1), stable=True)
+
+
+def draw_block(deg, b, e, n, items, seed, dev, perm):
+    """Unique sorted keys user * n + item of users b .. e: draw t of user u is a function of (seed, u, t) alone."""
+    from teamoflow_amd.mf.utils import counter_hash, hash_below, hash_unit
+    keys, cum = [], torch.cumsum(deg[b:e], 0)
+    u0 = b
+    while u0 < e:
+        # as many whole users as fit GEN_CHUNK_DRAWS draws (at least one)
+        base = int(cum[u0 - b - 1]) if u0 > b else 0
+        u1 = b + max(int(torch.searchsorted(cum, base + GEN_CHUNK_DRAWS, right=True)), u0 - b + 1)
+        u1 = min(u1, e)
+        d = deg[u0:u1]
+        total = int(d.sum())
+        u = torch.repeat_interleave(torch.arange(u0, u1, device=dev, dtype=torch.int64), d, output_size=total)
+        t = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(torch.cumsum(d, 0) - d, d, output_size=total)
+        h = counter_hash(seed, u, t, 3)
+        del t
+        if items == 'zipf':
+            ranks = torch.clamp(torch.pow(float(n + 1), hash_unit(h)).to(torch.int64) - 1, 0, n - 1)
+            j = perm[ranks]
+            del ranks
+        else:
+            j = hash_below(h, n)
+        del h
+        keys.append(torch.unique(u * n + j))
+        del u, j
+        u0 = u1
+    return torch.cat(keys) if len(keys) != 1 else keys[0]
+
+
+def calibrated_degrees(m, n, nnz_target, items, seed, dev):
+    """Drawn degrees of the whole problem such that the UNIQUE pairs come out within ~1 % of nnz_target.  Duplicate
+    (user, item) draws collapse (19 % of them at C4 with the power law), so the draw is inflated - calibrated on users
+    0 .. CALIBRATION_USERS (users are independent and identically distributed, so a prefix estimates the global rate),
+    never on the whole problem.  Deterministic: every rank arrives at the same vector."""
+    perm = item_permutation(n, dev) if items == 'zipf' else None
+    inflate, cal = 1.0, min(m, CALIBRATION_USERS)
+    for attempt in range(4):
+        deg = drawn_degrees(m, n, nnz_target, seed, dev, inflate)
+        unique_est = float(draw_block(deg, 0, cal, n, items, seed, dev, perm).numel()) / float(deg[:cal].sum()) * float(deg.sum())
+        if abs(unique_est - nnz_target) <= 0.005 * nnz_target:
+            break
+        inflate *= nnz_target / unique_est
+    return deg, perm
+
+
+def gen_interactions(m, n, nnz_target, items, seed, dev, users=None, plan=None):
     """Synthetic interactions of SURVEY.md §8d: user degrees lognormal(4.2, 0.8) rescaled to the
     target; item ids from a power law (alpha = 1) over a fixed permutation ('zipf') or uniform;
-    values in {1..5}; unique row-major pairs."""
-    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(4242))
-    inflate = 1.0
-    for attempt in range(4):
-        # duplicate (user, item) draws collapse (19 % of them at C4 with the power law), so the draw is repeated with
-        # an inflated target until the number of UNIQUE pairs is within 1 % of the requested nnz
-        g = torch.Generator(device=dev).manual_seed(1000 + seed)
-        deg = torch.exp(4.2 + 0.8 * torch.randn(m, device=dev, generator=g))
-        deg = torch.clamp(torch.round(deg * (nnz_target * inflate / float(deg.sum()))), 1, n // 4).to(torch.int64)
-        total = int(deg.sum())
-        u = torch.repeat_interleave(torch.arange(m, device=dev), deg, output_size=total)
-        if items == 'zipf':
-            x = torch.rand(total, device=dev, generator=g)
-            ranks = torch.clamp(torch.pow(float(n + 1), x).to(torch.int64) - 1, 0, n - 1)
-            j = perm[ranks]
-            del x, ranks
-        else:
-            j = torch.randint(0, n, (total,), device=dev, generator=g)
-        key = torch.unique(u * n + j)
-        del u, j
-        if key.numel() >= 0.99 * nnz_target:
-            break
-        inflate *= nnz_target / key.numel()
-    u, j = key // n, key % n
-    vals = torch.randint(1, 6, (key.numel(),), device=dev, generator=g).to(torch.float32)
-    return torch.stack([u, j], dim=1), vals
+    values in {1..5}; unique row-major pairs.
+
+    PER-USER SEEDED: the degree, item draws and values of user u are functions of (seed, u) only (counter_hash), so
+    `users=(b, e)` generates exactly that block of the m-user problem - the union over any partition of the users IS the
+    `users=None` problem, bit for bit (tests/test_bench_cpu.py) - and a rank of a strong-scaling job never builds more than
+    its own share.  The only global quantities are the O(m) degree vector and its duplicate-rate calibration
+    (`plan = calibrated_degrees(...)`), computed identically by every rank.
+    Returns (indices [nnz, 2] with GLOBAL user ids, values [nnz])."""
+    from teamoflow_amd.mf.utils import counter_hash, hash_below
+    deg, perm = plan if plan is not None else calibrated_degrees(m, n, nnz_target, items, seed, dev)
+    b, e = users if users is not None else (0, m)
+    key = draw_block(deg, b, e, n, items, seed, dev, perm)
+    vals = (1 + hash_below(counter_hash(seed, key, 7), 5)).to(torch.float32)
+    return torch.stack([key // n, key % n], dim=1), vals
 
 
 def init_table(rows, r, seed, dev):
@@ -146,8 +201,11 @@ def epoch_hbm_frac(models, seconds):
 
 def roofline_report(models, prof, pmc=None):
     """One entry per kernel: its measured duration (HIP events on the launch stream inside the timed region), the rate
-    it moves its gather bytes at against the L2 roof, its compulsory HBM bytes against the HBM roof, and - when a
-    PMC profile of this code version is committed - the measured fabric traffic.  No entry carries a fraction > 1."""
+    it moves its gather bytes at against the L2 roof, its compulsory HBM bytes against the HBM roof (`useful_hbm_frac`), and -
+    when a PMC profile of this code version is committed - the measured fabric traffic and how many times the compulsory
+    bytes it is (`traffic_over_compulsory`).  Fractions are RAW ratios, never clamped: a measured fabric rate above the
+    6.29 TB/s the guide measures for an HBM copy cannot all be HBM bytes (FETCH_SIZE counts Infinity-Cache hits), so such a
+    kernel is labelled `bound: fabric` and priced against the guide's 8.6 TB/s Infinity-Cache gather rate."""
     entries = []
     for name, k in models.items():
         ms = prof.mean_ms(name)
@@ -155,48 +213,56 @@ def roofline_report(models, prof, pmc=None):
             continue
         t = ms * 1e-3
         e = dict(kernel=name, ms=ms, what=k['what'], hbm_bytes=k['hbm'], hbm_rate_GBps=k['hbm'] / t / 1e9,
-                 hbm_frac=k['hbm'] / t / HBM_PEAK)
+                 hbm_frac=k['hbm'] / t / HBM_PEAK, useful_hbm_frac=k['hbm'] / t / HBM_PEAK)
         if k['gather']:
             e.update(rows_gathered=k['rows'], gather_bytes=k['gather'], gather_rate_GBps=k['gather'] / t / 1e9,
                      l2_frac=k['gather'] / t / L2_PEAK)
         meas = pmc.get(name) if pmc else None
-        if k['roof'] == 'l2' and meas is not None and meas['bytes'] / t / HBM_PEAK >= FABRIC_BOUND_FROM and meas['bytes'] / t / HBM_PEAK > e['l2_frac']:
+        rate = meas['bytes'] / t if meas is not None else None
+
+        def fabric(extra=''):
+            e.update(bound=FABRIC_LABEL, achieved=rate / 1e9, peak=FABRIC_GATHER_MEASURED / 1e9, frac=rate / FABRIC_GATHER_MEASURED,
+                     frac_source='pmc', hbm_peak_frac=rate / HBM_PEAK,
+                     note=f"measured fabric rate {rate / 1e12:.2f} TB/s (L2-miss + write traffic, L2 hit rate {meas.get('l2_hit_rate')}) is above the "
+                          f"{HBM_COPY_MEASURED / 1e12:.2f} TB/s the guide measures for a float4 copy from HBM: FETCH_SIZE counts Infinity-Cache "
+                          f"hits too, so these are NOT all HBM bytes; priced against the guide's {FABRIC_GATHER_MEASURED / 1e12:.1f} TB/s "
+                          f"Infinity-Cache row-gather rate; traffic is {meas['bytes'] / k['hbm']:.1f}x the compulsory bytes" + extra)
+        if k['roof'] == 'l2' and rate is not None and rate / HBM_PEAK >= FABRIC_BOUND_FROM and rate / HBM_PEAK > e['l2_frac']:
             # blocked for the L2s, but the counters say the memory-side fabric is the roof that binds (config-5 shard: L2 hit rate
             # 0.41, 7 - 9 TB/s of fabric traffic - at or above the measured copy ceiling): price the kernel where it is bound.
             # (The C4 item pass moves 4.5 TB/s over the fabric - 0.56 of the peak, more than its L2 fraction, but nowhere near a
             # roof: it stays on the L2 roof it is built against.)
-            rate = meas['bytes'] / t
-            e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=min(rate / HBM_PEAK, 1.0), frac_source='pmc',
-                     note=f"blocked for the L2s (gather rate {e['gather_rate_GBps'] / 1e3:.1f} TB/s = {e['l2_frac']:.2f} of the L2 roof) but bound by the "
-                          f"memory-side fabric: measured {rate / 1e12:.2f} TB/s of L2-miss + write traffic, L2 hit rate {meas.get('l2_hit_rate')}; "
-                          "FETCH_SIZE counts Infinity-Cache hits too, so this is fabric traffic, of which HBM is an unknown share")
+            if rate > HBM_COPY_MEASURED:
+                fabric(f"; blocked for the L2s (gather rate {e['gather_rate_GBps'] / 1e3:.1f} TB/s = {e['l2_frac']:.2f} of the L2 roof)")
+            else:
+                e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=rate / HBM_PEAK, frac_source='pmc',
+                         note=f"blocked for the L2s (gather rate {e['gather_rate_GBps'] / 1e3:.1f} TB/s = {e['l2_frac']:.2f} of the L2 roof) but bound by "
+                              f"the memory side: measured {rate / 1e12:.2f} TB/s of L2-miss + write traffic, L2 hit rate {meas.get('l2_hit_rate')}")
         elif k['roof'] == 'l2':
             e.update(bound='l2', achieved=e['gather_rate_GBps'], peak=L2_PEAK / 1e9, frac=e['l2_frac'])
         elif k['roof'] == 'hbm' and meas is not None:
             # HBM-bound kernel with counters of this code version: the fraction is MEASURED fabric bytes (L2 misses + writes,
-            # FETCH_SIZE / WRITE_SIZE) over the kernel's time against the 8 TB/s peak - not the byte model
-            rate = meas['bytes'] / t
-            e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=min(rate / HBM_PEAK, 1.0), frac_source='pmc',
-                     hbm_model_frac=e['hbm_frac'])
+            # FETCH_SIZE / WRITE_SIZE) over the kernel's time - not the byte model
             if rate > HBM_COPY_MEASURED:
-                e['note'] = (f"measured fabric rate {rate / 1e12:.2f} TB/s is above the {HBM_COPY_MEASURED / 1e12:.2f} TB/s the guide measures for a "
-                             f"float4 copy from HBM: FETCH_SIZE counts Infinity-Cache hits too, so part of it is served by the 256 MiB cache "
-                             f"(L2 hit rate {meas.get('l2_hit_rate')}); the HBM share cannot be separated with the exposed counters")
+                fabric()
+            else:
+                e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=rate / HBM_PEAK, frac_source='pmc')
+            e['hbm_model_frac'] = e['hbm_frac']
         elif k['roof'] == 'hbm' and e['hbm_frac'] > 1.0 and k['gather']:
             # no counters for this code version and the no-reuse model (every gathered row of a table beyond the Infinity Cache comes
             # from HBM) exceeds the peak: rows are re-served on chip.  Price the kernel on the L2 roof and say so.
             e.update(bound='l2', achieved=e['gather_rate_GBps'], peak=L2_PEAK / 1e9, frac=e['l2_frac'],
                      note=f"UNVALIDATED byte model: without reuse it would give {e['hbm_frac']:.2f} of the HBM peak, so rows are served on chip; "
                           "no PMC profile of this code version to say how many")
-            e['hbm_frac'] = None
+            e['hbm_frac'] = e['useful_hbm_frac'] = None
         elif k['roof'] == 'hbm':
             e.update(bound='hbm', achieved=e['hbm_rate_GBps'], peak=HBM_PEAK / 1e9, frac=e['hbm_frac'], frac_source='byte model (no counters)')
         else:
             e.update(bound='issue', achieved=e['hbm_rate_GBps'], peak=HBM_PEAK / 1e9, frac=e['hbm_frac'],
                      note='instruction-issue / LDS-latency bound; the HBM figure only shows it is far from that roof')
         if meas is not None:
-            e.update(traffic=meas['bytes'], hbm_traffic_frac=min(meas['bytes'] / t / HBM_PEAK, 1.0),
-                     traffic_uncorrected=meas['bytes_uncorrected'], traffic_rate_GBps=meas['bytes'] / t / 1e9,
+            e.update(traffic=meas['bytes'], hbm_traffic_frac=rate / HBM_PEAK, traffic_over_compulsory=meas['bytes'] / k['hbm'],
+                     traffic_uncorrected=meas['bytes_uncorrected'], traffic_rate_GBps=rate / 1e9,
                      l2_hit_rate=meas.get('l2_hit_rate'))
         entries.append(e)
     entries.sort(key=lambda e: -e['ms'])
@@ -386,6 +452,77 @@ def small_configs(dev, quick=False):
     return out
 
 
+LINE_HARD_CAP = 8192   # bytes: the driver keeps only a tail of stdout, so the ONE line must stay small (round 3's 20.5 KB line was cut)
+LINE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+             'data', 'config', 'roofline', 'cpu_baseline', 'predict_rows_per_sec', 'predict_tflops', 'predict_arithmetic',
+             'predict_top10_rows_identical_to_fp64', 'recall_at_10',
+             'hinge_terms_per_sec', 'collectives', 'extras')
+ROOFLINE_KEYS = ('bound', 'kernel', 'kernel_ms', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'hbm_traffic_frac', 'traffic_over_compulsory',
+                 'useful_hbm_frac', 'l2_hit_rate', 'traffic_source', 'csrc_sha', 'epoch_hbm_frac', 'kernels_ms')
+
+
+def _short(x, digits=6):
+    """Floats to `digits` significant digits (the full-precision numbers are in the extras file)."""
+    if isinstance(x, float):
+        return float(f'{x:.{digits}g}') if x == x and abs(x) != float('inf') else None
+    if isinstance(x, dict):
+        return {k: _short(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, digits) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The ONE JSON line of the bench contract, cut down to what the driver and the judge read (target <= 4 KB, hard cap
+    LINE_HARD_CAP): headline metric, config, the dominant kernel's roofline entry, the CPU baseline, the ranking numbers.
+    Everything else of `out` (per-kernel entries, HBM legs, projection, per-arithmetic predict table, API fit, small configs,
+    notes) goes to the extras file (write_extras)."""
+    line = {k: out[k] for k in LINE_KEYS if k in out}
+    cfg = out.get('config', {})
+    line['config'] = {k: cfg[k] for k in ('workload', 'interactions_total', 'interactions_per_gpu', 'parallelism', 'lr') if k in cfg}
+    r = out.get('roofline', {})
+    roof = {k: r.get(k) for k in ROOFLINE_KEYS if k in r}
+    if 'kernels' in r:
+        roof['kernels_ms'] = {e['kernel']: [round(e['ms'], 3), e['bound'].split(' ')[0], round(e['frac'], 3) if e.get('frac') is not None else None]
+                              for e in r['kernels']}
+    line['roofline'] = roof
+    if 'cpu_baseline' in out:
+        c = out['cpu_baseline']
+        line['cpu_baseline'] = {k: c[k] for k in ('value', 'unit', 'cores', 'kind') if k in c}
+        line['cpu_baseline']['sample'] = str(c.get('sample', ''))[:240]
+    if 'recall_at_10' in out:
+        q = out['recall_at_10']
+        line['recall_at_10'] = {k: q[k] for k in ('engine', 'oracle', 'abs_diff') if k in q}
+        if 'end_to_end_C2' in q:
+            line['recall_at_10']['end_to_end_C2_abs_diff'] = q['end_to_end_C2'].get('abs_diff')
+    if 'collectives' in out:
+        c = out['collectives']
+        line['collectives'] = {k: v for k, v in c.items() if not isinstance(v, (dict, list, str)) or k in ('backend',)}
+    line = _short(line)
+    text = json.dumps(line, separators=(',', ':'))
+    if len(text) > LINE_HARD_CAP:   # never print a line the driver cannot take: drop the optional parts, largest first
+        for k in ('collectives', 'hinge_terms_per_sec', 'extras'):
+            line.pop(k, None)
+        line['roofline'].pop('kernels_ms', None)
+        line['cpu_baseline'] = {k: v for k, v in line.get('cpu_baseline', {}).items() if k != 'sample'}
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) <= LINE_HARD_CAP, len(text)
+    return text
+
+
+def write_extras(out, path=None):
+    """Everything the bench measured, in full, beside the compact line: gpurun_out/bench_extras.json (TMF_BENCH_EXTRAS overrides)."""
+    path = path or os.environ.get('TMF_BENCH_EXTRAS') or os.path.join(ROOT, 'gpurun_out', 'bench_extras.json')
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(out, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        log(f'[bench] extras not written: {e!r}')
+        return None
+
+
 class Workload:
     """One rank's problem, resident in HBM: interactions, negative table, plans, factor tables."""
 
@@ -401,16 +538,17 @@ class Workload:
         trace('start')
         n_pad = tdist.padded_rows(n, world)
         if strong and world > 1:
-            # the ONE global problem, cut into contiguous user blocks of balanced cost (interactions + negatives)
-            idx, val = gen_interactions(m, n, nnz_target, args.item_dist, 0, dev)
-            deg = torch.bincount(idx[:, 0], minlength=m)
-            bounds = tdist.partition_users(_engine._excl_cumsum(deg), world, per_user_cost=S if loss == 'wmrb' else 0)
+            # the ONE global problem, cut into contiguous user blocks of balanced cost (drawn interactions + negatives).  Every
+            # rank computes the O(m) degree vector and generates ONLY its own block (gen_interactions is per-user seeded)
+            gplan = calibrated_degrees(m, n, nnz_target, args.item_dist, 0, dev)
+            bounds = tdist.partition_users(_engine._excl_cumsum(gplan[0]), world, per_user_cost=S if loss == 'wmrb' else 0)
             b, e = bounds[rank], bounds[rank + 1]
-            keep = (idx[:, 0] >= b) & (idx[:, 0] < e)
-            idx, val = _engine.take_interactions(idx, val, keep, user_offset=b)
+            idx, val = gen_interactions(m, n, nnz_target, args.item_dist, 0, dev, users=(b, e), plan=gplan)
+            idx[:, 0] -= b
             U0 = init_table(m, r, 11, dev)[b:e].clone()
             self.user_block, m = (b, e), e - b
-            trace('interactions of the global problem cut')
+            del gplan
+            trace('own block of the global problem generated')
         else:
             idx, val = gen_interactions(m, n, nnz_target, args.item_dist, rank, dev)
             U0 = init_table(m, r, 11 + rank, dev)
@@ -427,9 +565,8 @@ class Workload:
         trace('interaction plan built')
         if loss == 'wmrb':
             if strong and world > 1:
-                # the ONE problem: its negative table is the table of the N = 1 run (seed 100), of which this rank keeps its users' rows
-                b, e = self.user_block
-                self.R = random_sampler_device(n, args.users, S, seed=100, device=dev)[b:e].contiguous()
+                # the ONE problem: its negative table is the table of the N = 1 run (seed 100), of which this rank draws its users' rows
+                self.R = random_sampler_device(n, m, S, seed=100, device=dev, user_offset=self.user_block[0])
             else:
                 self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
             trace('negative table drawn')
@@ -694,7 +831,8 @@ def sharded_run(args, rank, world, dev, rehearse, red_dev, json_out):
                                 note='per window: all-gather of the rows (async, prefetched one window ahead), reduce-scatter of the fp32 '
                                      'gradient (async); overlapped with the window\'s kernels'),
                loss_first_last=[lh[0], lh[-1]])
-    print(json.dumps(out), file=json_out, flush=True)
+    out['extras'] = write_extras(out)
+    print(compact_line(out), file=json_out, flush=True)
 
 
 def main():
@@ -793,6 +931,8 @@ def main():
     top = kernels[0]
     roofline = dict(bound=top['bound'], kernel=top['kernel'], achieved=top['achieved'], peak=top['peak'], unit='GB/s', frac=top['frac'],
                     traffic=top.get('traffic'), hbm_traffic_frac=top.get('hbm_traffic_frac'), traffic_source=pmc_src,
+                    traffic_over_compulsory=top.get('traffic_over_compulsory'), useful_hbm_frac=top.get('useful_hbm_frac'),
+                    l2_hit_rate=top.get('l2_hit_rate'),
                     kernel_ms=top['ms'], kernels=kernels, csrc_sha=csrc_sha(),
                     epoch_hbm_bytes=sum(k['hbm'] for k in models.values()),
                     epoch_hbm_frac=epoch_hbm_frac(models, ms_per_step * 1e-3),
@@ -848,14 +988,14 @@ def main():
             _ops.predict_topk(Ue[:rows], Ve, 10, clamp_negatives=True, arithmetic=arith)
             torch.cuda.synchronize()
             return time.perf_counter() - t1
-        # what the class surface runs at this size (arithmetic='auto'): for fp32 tables of width <= 128 the ranking goes to the
-        # 16-bit matrix cores with fp32 accuracy - two fp16 planes per factor under power-of-two scales, three plane products
-        # (tmf_predict_topk_half2_f32), or three bf16 planes and six products when the item rows span more than 2^12 in
-        # magnitude (tmf_predict_topk_split_f32); else the fp32 / bf16 MFMA kernels
+        # what the class surface runs at this size (arithmetic='auto'): fp32 tables keep ALL 24 bits of every factor - on the
+        # bf16 matrix cores as three exact bf16 planes and six exact plane products (tmf_predict_topk_split_f32) where that
+        # kernel applies (width <= 128, k <= 32), else on the fp32 MFMA; bf16 tables on the bf16 MFMA.  The two-plane fp16
+        # form (22 bits) is an opt-in approximation: timed below for the extras file, never the headline
         dt = time_topk(None)
         flops = 2.0 * rows * wl.n * wl.r
         planes = args.dtype != 'bf16' and _ops.split_topk_supported(wl.r, 10) and rows * wl.n >= _ops.SPLIT_MIN_SCORES
-        chosen = ('half2' if _ops.half2_range_ok(Ve) else 'split') if planes else ('bf16' if args.dtype == 'bf16' else 'fp32')
+        chosen = 'split' if planes else ('bf16' if args.dtype == 'bf16' else 'fp32')
         out['predict_rows_per_sec'] = rows / dt
         out['predict_tflops'] = flops / dt / 1e12
         out['predict_arithmetic'] = chosen
@@ -882,8 +1022,9 @@ def main():
                                  top10_rows_identical_to_fp64=float((i.long() == torch.topk(ref, 10, dim=1)[1]).all(1).float().mean()))
             del ref
             out['predict_by_arithmetic'] = dict(by, err_sample_users=sample,
-                                                note="model.predict_arithmetic = 'fp32' | 'split' | 'half2' selects; errors of the returned "
-                                                     'top-10 values against an fp64 product of the same tables')
+                                                note="model.predict_arithmetic = 'fp32' | 'split' | 'half2' selects ('auto' never takes the 22-bit "
+                                                     "'half2'); errors of the returned top-10 values against an fp64 product of the same tables")
+            out['predict_top10_rows_identical_to_fp64'] = by[chosen]['top10_rows_identical_to_fp64']
             out['predict_fp32_mfma'] = dict(rows_per_sec=by['fp32']['rows_per_sec'], tflops=by['fp32']['tflops_fp32_equivalent'])
         got, want = recall_parity(dev)
         out['recall_at_10'] = dict(engine=got, oracle=want, abs_diff=abs(got - want),
@@ -928,7 +1069,12 @@ def main():
             c5_shard_bf16=hbm_leg(args, dev, 'config-5 shard (1/8 of 10M x 1M)', 1_250_000, 1_000_000, 125_000_000, 256, 1024, 'wmrb',
                                   'bf16', 5, 2, 'c5_shard_bf16'))
     if rank == 0:
-        print(json.dumps(out), file=json_out, flush=True)
+        out['extras'] = write_extras(out)
+        log('[bench] roofline kernels: ' + json.dumps(_short({e['kernel']: dict(ms=e['ms'], bound=e['bound'], frac=e['frac'],
+                                                                               traffic_over_compulsory=e.get('traffic_over_compulsory'),
+                                                                               useful_hbm_frac=e.get('useful_hbm_frac'))
+                                                             for e in out['roofline']['kernels']}, 4)))
+        print(compact_line(out), file=json_out, flush=True)
     if dp_mode:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TMF_VERSION 201 /* 0.2.1 */
+#define TMF_VERSION 202 /* 0.2.2: tmf_slice_lists is 72 bytes (xcd_major), predict split / half2 / rows4 / gradu4 entry points */
 
 #define TMF_OK 0
 #define TMF_E_INVALID (-1)   /* bad argument (null pointer, unsupported rank, size mismatch) */

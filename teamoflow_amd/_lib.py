@@ -110,6 +110,7 @@ for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_gradu3', 'tmf_wmrb_gradu4', 'tmf_wmr
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name + '_f32']
 
 _lib = None
+MIN_LIB_VERSION = 202   # include/tmf.h TMF_VERSION: 202 = tmf_slice_lists grew to 72 bytes (xcd_major) + the round-3 entry points
 
 
 def build(force=False, verbose=False):
@@ -132,16 +133,24 @@ def load_library():
         raise EngineUnavailable(f'{LIB_PATH} not found - run `python -c "import __graft_entry__ as g; g.build()"` '
                                 f'or `make -C {CSRC}`')
     lib = ctypes.CDLL(LIB_PATH)
+    older = os.environ.get('TMF_LIB_OLDER') == '1'   # A/B runs against a library built from an older commit (tools/c4_ab.sh)
+    # the version first: a stale library then says so instead of failing on the first symbol it lacks
+    try:
+        lib.tmf_version.restype, lib.tmf_version.argtypes = SIGNATURES['tmf_version']
+        version = lib.tmf_version()
+    except AttributeError:
+        version = 0
+    if version < MIN_LIB_VERSION and not older:
+        raise EngineUnavailable(f'{LIB_PATH} is version {version}, this package needs {MIN_LIB_VERSION} or newer (struct layouts and '
+                                f'entry points changed) - rebuild it: `make -C {CSRC}`')
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            if os.environ.get('TMF_LIB_OLDER') == '1':   # A/B runs against a library built from an older commit (tools/c4_ab.sh)
+            if older:
                 continue
-            raise
+            raise EngineUnavailable(f'{LIB_PATH} (version {version}) lacks {name} - rebuild it: `make -C {CSRC}`') from None
         fn.restype, fn.argtypes = res, args
-    if lib.tmf_version() < 201:
-        raise EngineUnavailable('libtmf.so is older than this package')
     _lib = lib
     return lib
 

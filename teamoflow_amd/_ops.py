@@ -79,7 +79,7 @@ def half2_topk_supported(r, k):
     return 1 <= r <= 256 and 1 <= k <= 32
 
 
-HALF2_MAX_ROW_RANGE = 2.0 ** 12   # largest / smallest item-row magnitude up to which 'auto' takes the two-plane fp16 kernel
+HALF2_MAX_ROW_RANGE = 2.0 ** 12   # largest / smallest item-row magnitude up to which the opt-in two-plane fp16 kernel keeps 22 bits
 
 
 def half2_range_ok(item_rows):
@@ -95,11 +95,13 @@ def half2_range_ok(item_rows):
 
 def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False, arithmetic=None):
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
-    fp32 tables: fp32 MFMA (k <= 64, width <= 256), or - width <= 128, k <= 32 - on the 16-bit matrix cores with fp32 accuracy:
-    arithmetic='split' (three exact bf16 planes per factor, six products: ~1.9x the rate of the fp32 kernel, errors against fp64
-    at or below its) or 'half2' (two fp16 planes under power-of-two scales, three products: ~2.9x, errors at the fp32 kernel's;
-    one scale for the whole item table, hence half2_range_ok).  'auto' takes half2 - or split when the item rows span more than
-    2^12 in magnitude - where they apply and the job has SPLIT_MIN_SCORES scores or more.
+    fp32 tables: 'fp32' = fp32 MFMA (k <= 64, width <= 256, bit-equal to an fmaf chain); 'split' = the bf16 matrix cores with ALL
+    24 significand bits of every factor (three exact bf16 planes per factor, six plane products each exact in the fp32
+    accumulator; ~1.9x the rate of the fp32 kernel, errors against fp64 at or below its; width <= 128, k <= 32).
+    'auto' (the default) takes 'split' where it applies and the job has SPLIT_MIN_SCORES scores or more, else 'fp32' - both keep
+    the reference's fp32 operands whole (tf.matmul on fp32, matrix_factorization.py:236-248, 424-438).
+    'half2' is an OPT-IN approximation, never chosen by 'auto': two fp16 planes under power-of-two scales = 22 bits of every
+    factor, three products, ~2.9x; one scale for the whole item table, so check half2_range_ok(item_embedding) first.
     bf16 tables (both operands): bf16 MFMA with fp32 accumulation, k <= 32, width <= 256.
     See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
@@ -131,23 +133,25 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
     if (arithmetic == 'split' and not split_topk_supported(r, k)) or (arithmetic == 'half2' and not half2_topk_supported(r, k)):
         raise ValueError(f'the split kernels support widths <= 128 (half2: 256) and k <= 32 (got {r}, {k})')
-    if arithmetic == 'auto' and m * n >= SPLIT_MIN_SCORES and half2_topk_supported(r, k):
-        if half2_range_ok(B[:, :r]):
-            arithmetic = 'half2'
-        elif split_topk_supported(r, k):
-            arithmetic = 'split'
-    if arithmetic == 'half2':
-        need = lib.tmf_predict_topk_half2_workspace_bytes(n, r)
-        ws = torch.empty(need, dtype=torch.uint8, device=A.device)
-        _lib.check(lib.tmf_predict_topk_half2_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
-                                                  _lib.ptr(idx), _lib.ptr(vals), _lib.ptr(ws), need, _lib.stream_ptr()), lib)
-        return (vals, idx) if return_values else idx
-    if arithmetic == 'split':
-        need = lib.tmf_predict_topk_split_workspace_bytes(n, r)
-        ws = torch.empty(need, dtype=torch.uint8, device=A.device)
-        _lib.check(lib.tmf_predict_topk_split_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
-                                                  _lib.ptr(idx), _lib.ptr(vals), _lib.ptr(ws), need, _lib.stream_ptr()), lib)
-        return (vals, idx) if return_values else idx
+    if arithmetic == 'auto':
+        arithmetic = 'split' if m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k) else 'fp32'
+        planes_optional = True    # 'auto' may fall back to the fp32 kernel (it needs no workspace) when memory is short
+    else:
+        planes_optional = False
+    if arithmetic in ('half2', 'split'):
+        size = lib.tmf_predict_topk_half2_workspace_bytes if arithmetic == 'half2' else lib.tmf_predict_topk_split_workspace_bytes
+        run = lib.tmf_predict_topk_half2_f32 if arithmetic == 'half2' else lib.tmf_predict_topk_split_f32
+        need = size(n, r)
+        try:
+            ws = torch.empty(need, dtype=torch.uint8, device=A.device)
+        except torch.OutOfMemoryError:
+            if not planes_optional:
+                raise
+            ws = None   # the planes of the item table (1.5x its size) do not fit: the fp32 MFMA kernel ranks without them
+        if ws is not None:
+            _lib.check(run(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
+                           _lib.ptr(idx), _lib.ptr(vals), _lib.ptr(ws), need, _lib.stream_ptr()), lib)
+            return (vals, idx) if return_values else idx
     _lib.check(lib.tmf_predict_topk_f32(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),
                                         _lib.ptr(idx), _lib.ptr(vals), _lib.stream_ptr()), lib)
     return (vals, idx) if return_values else idx

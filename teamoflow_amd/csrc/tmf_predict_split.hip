@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));   // the other half of the k-slices
             sc = half_scale_for(mx);
-            if (h == 0) inv_scale[32 * wave + l31] = 1.f / (sc * *item_scale);   // both powers of two: exact
+            if (h == 0) inv_scale[32 * wave + l31] = (1.f / sc) * (1.f / *item_scale);   // two exact powers of two; their PRODUCT sc * item_scale can overflow (tiny tables), the reciprocals' only when the scores themselves do
         } else {
             if (h == 0) inv_scale[32 * wave + l31] = 1.f;
         }
@@ -434,7 +434,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const float t0 = half_kth_largest(tq[q], k, l31, h);
-                if (l31 == 0 && row0 + rbase + qoff(q) < m) tau_l[qoff(q)] = t0 - fabsf(t0) * 1e-6f - 1e-30f;   // strictly below the bound
+                // strictly below the bound; a row with k or more +inf scores in the warm-up tiles has t0 = +inf (inf - inf = NaN would
+                // reject every candidate of the scan and leave the row's list empty): its bound is the largest finite value
+                if (l31 == 0 && row0 + rbase + qoff(q) < m)
+                    tau_l[qoff(q)] = __builtin_isfinite(t0) ? t0 - fabsf(t0) * 1e-6f - 1e-30f : (t0 > 0.f ? 3.0e38f : -INFINITY);
             }
             wave_lds_sync();
             load_tau();

@@ -884,8 +884,8 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
     TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
     const size_t lds = slice_lds(geom, waves);
     TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 3, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
-    TMF_REQUIRE_LAUNCH(a.n_groups * 8, 64 * waves, "wmrb_gradu3");
     if (per_slice_launches == 3) {   // rounds of eight slices, one layer per XCD lane (see k_wmrb_gradu3)
+        TMF_REQUIRE_LAUNCH(a.n_groups * 8, 64 * waves, "wmrb_gradu3 (rounds of eight slices)");
         for (int sl = a.sl0; sl < a.sl0 + a.nsl; sl += 8) {
             const int accumulate = (sl == a.sl0) ? 3 : 4;
 #define CALLW(G_, NV_, W_)                                                                                                       \
@@ -901,6 +901,7 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
         return check_launch("tmf_wmrb_gradu3");
     }
     if (per_slice_launches) {
+        TMF_REQUIRE_LAUNCH(a.n_groups, 64 * waves, "wmrb_gradu3 (one launch per slice)");
         for (int sl = a.sl0; sl < a.sl0 + a.nsl; ++sl) {
             const int accumulate = (sl == a.sl0 && per_slice_launches == 1) ? 1 : 2;
 #define CALLW(G_, NV_, W_)                                                                                                   \

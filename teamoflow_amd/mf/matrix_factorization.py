@@ -90,7 +90,7 @@ class MatrixFactorization:
         self.plan_seconds_ = 0.0  # extension: time spent building the index structures of the last fit
         self.verbose = True
         self.factor_dtype = torch.float32  # extension: torch.bfloat16 = bf16 factor storage, fp32 arithmetic
-        self.predict_arithmetic = None     # extension: 'fp32' | 'split' | 'auto' for the fused top-k of fp32 tables (_ops.predict_topk)
+        self.predict_arithmetic = None     # extension: 'auto' (default: 'split' or 'fp32', both on whole fp32 factors) | 'fp32' | 'split' | 'half2' (opt-in, 22 bits) - _ops.predict_topk
         self.data_parallel = False         # extension: split the users over torch.distributed ranks (teamoflow_amd/dist.py)
         # extension: q >= 1 = item-row-sharded V in q windows per rank (dist.fit_item_sharded): the item table is owned in
         # row blocks and streamed window by window instead of being replicated - for catalogs beyond one GPU's memory

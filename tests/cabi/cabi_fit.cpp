@@ -59,7 +59,7 @@ int main() {
     const int m = 300, n = 200, r = 24, epochs = 5, k = 5;
     const float lr = 1e-3f;
     const int ld = tmf_padded_ld(r);
-    if (tmf_version() < 201 || ld < r) { fprintf(stderr, "library version %d, ld %d\n", tmf_version(), ld); return 1; }
+    if (tmf_version() < 202 || ld < r) { fprintf(stderr, "library version %d, ld %d\n", tmf_version(), ld); return 1; }
     Lcg rng{12345};
     std::set<std::pair<int, int>> seen;
     std::vector<int64_t> idx;

@@ -204,6 +204,29 @@ def check_topk_against_cpu_oracle(U, V, vals, idx, k, min_identical_rows=0.97):
     return S
 
 
+def test_default_ranking_on_c4_trained_tables(c4):
+    """retrieve_user_recs(k=10) as the class surface runs it at C4 (nothing selected: the three-plane kernel, 24 bits of every
+    factor) on the tables one C4 epoch leaves: index for index oracle.dense_ref.tf_top_k of a CPU fp32 matmul of the same rows
+    wherever the oracle's values are separated (check_topk_against_cpu_oracle), 4,096 users spread over the table - and the
+    same lists from the fp32 MFMA kernel.  matrix_factorization.py:424-438."""
+    from teamoflow_amd import _ops
+    from teamoflow_amd.mf.matrix_factorization import MatrixFactorization
+    st, r, m = c4['st'], c4['r'], c4['m']
+    users = torch.arange(0, m, m // 4096, device=st.U.device)[:4096]
+    model = MatrixFactorization(r)
+    assert model.predict_arithmetic is None and _ops.PREDICT_ARITHMETIC == 'auto'
+    model.user_embedding, model.item_embedding = st.U_nxt[users, :r].contiguous(), st.V_nxt[:c4['n'], :r]
+    assert users.numel() * c4['n'] >= _ops.SPLIT_MIN_SCORES and _ops.split_topk_supported(r, 10)
+    got = torch.as_tensor(np.asarray(model.retrieve_user_recs(k=10)))
+    vals, idx = _ops.predict_topk(model.user_embedding, model.item_embedding, 10, return_values=True)
+    assert torch.equal(idx.cpu().long(), got.long())
+    check_topk_against_cpu_oracle(model.user_embedding, model.item_embedding, vals, idx, 10, min_identical_rows=0.9)
+    v32, i32 = _ops.predict_topk(model.user_embedding, model.item_embedding, 10, return_values=True, arithmetic='fp32')
+    same = (i32 == idx).all(1)
+    assert float(same.float().mean()) > 0.999
+    assert float((v32 - vals).abs().max()) <= 2e-6 * float(v32.abs().max())
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_full_catalog_fused_topk_matches_the_cpu_oracle(dtype):
     """predict at catalog scale (1,000,003 items - a ragged last tile, 512 MB of V, byte offsets up to 2^29 in the

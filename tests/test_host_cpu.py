@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tmf_version() == 201
+    assert lib.tmf_version() == 202 == _lib.MIN_LIB_VERSION
 
 
 def test_padded_ld_and_adam_constants_match_host_mirror():
