@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'liboracle_sparse.so')
+# ORACLE_SPARSE_LIB: another build of the same file (the sanitized one of `make -C oracle asan`)
+LIB_PATH = os.environ.get('ORACLE_SPARSE_LIB') or os.path.join(HERE, 'liboracle_sparse.so')
 _lib = None
 
 

@@ -102,6 +102,8 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     the reference's fp32 operands whole (tf.matmul on fp32, matrix_factorization.py:236-248, 424-438).
     'half2' is an OPT-IN approximation, never chosen by 'auto': two fp16 planes under power-of-two scales = 22 bits of every
     factor, three products, ~2.9x; one scale for the whole item table, so check half2_range_ok(item_embedding) first.
+    Scores BEYOND the fp32 range: the fp32 kernel returns +-inf like tf.matmul; the plane kernels may form +inf - inf = NaN between
+    plane products of opposite sign, and a NaN score is never ranked (the ids returned are those of the finite scores).
     bf16 tables (both operands): bf16 MFMA with fp32 accumulation, k <= 32, width <= 256.
     See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()

@@ -1,7 +1,8 @@
 // A compiled caller of the C ABI (include/tmf.h) with no Python and no torch in the process: builds the index
 // structures, runs MSE epochs (matrix_factorization.py:130-176 with MSELoss), a fused predict + top-k and WMRB epochs
 // (the sliced scores / hinge / gradU / finish kernels and the item-side gather-sum) on the GPU
-// through libtmf.so, and checks the results against a plain fp64 restatement kept in this file (test infrastructure).
+// through libtmf.so, and checks the results against the plain fp64 restatement of tests/cabi/host_ref.h (test infrastructure;
+// the same header is built stand-alone under AddressSanitizer / UBSan by tests/test_oracle_sanitized.py).
 // Built by tests/cabi/Makefile (hipcc; only the HIP runtime API is used on the host side), run by
 // tests/test_gpu_cabi.py.  Exit code 0 = every check passed.
 #include <hip/hip_runtime.h>
@@ -16,6 +17,7 @@
 #include <utility>
 #include <vector>
 
+#include "host_ref.h"
 #include "tmf.h"
 
 #define HIP_OK(x)                                                                         \
@@ -43,17 +45,9 @@ static std::vector<T> host_copy(const T* d, size_t n) {
     return h;
 }
 
-struct Lcg {
-    uint64_t s;
-    uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); }
-    float unit() { return (next() & 0xffffff) / 16777216.0f; }
-};
+using host_ref::Lcg;
 
-// fresh Keras-Adam step in fp32, as SURVEY.md A.1 spells it out
-static float adam_fresh(float w, float g, const tmf_adam& a) {
-    const float m = g * a.one_minus_b1, v = g * g * a.one_minus_b2;
-    return w - (m * a.alpha) / (sqrtf(v) + a.eps);
-}
+static host_ref::AdamT1 ref_adam(const tmf_adam& a) { return host_ref::AdamT1{a.alpha, a.one_minus_b1, a.one_minus_b2, a.eps}; }
 
 int main() {
     const int m = 300, n = 200, r = 24, epochs = 5, k = 5;
@@ -64,10 +58,7 @@ int main() {
     std::set<std::pair<int, int>> seen;
     std::vector<int64_t> idx;
     std::vector<float> val;
-    while ((int)seen.size() < 3000) {
-        const int u = rng.next() % m, j = rng.next() % n;
-        if (seen.insert({u, j}).second) { idx.push_back(u); idx.push_back(j); val.push_back(1.f + rng.next() % 5); }
-    }
+    host_ref::draw_interactions(rng, m, n, 3000, idx, val, seen);
     const int64_t nnz = (int64_t)val.size();   // in insertion (i.e. arbitrary) order: tmf_csr_build sorts
     std::vector<float> U((size_t)m * ld, 0.f), V((size_t)n * ld, 0.f);
     for (int i = 0; i < m; ++i) for (int c = 0; c < r; ++c) U[(size_t)i * ld + c] = 0.3f * (rng.unit() - 0.5f);
@@ -88,6 +79,7 @@ int main() {
     const auto rowptr_u = host_copy(d_rowptr_u, m + 1), rowptr_i = host_copy(d_rowptr_i, n + 1), perm = host_copy(d_perm, nnz);
     const auto col_u = host_copy(d_col_u, nnz), user_of = host_copy(d_user_of, nnz);
     const auto val_u = host_copy(d_val_u, nnz);
+    const host_ref::Problem P{m, n, r, ld, rowptr_u, col_u, user_of, val_u};   // the restatement works on the CSR the device built (checked below)
     int bad = 0;
     for (int u = 0; u < m; ++u)     // CSR: users ascending, items ascending inside a user, every pair present
         for (int64_t q = rowptr_u[u]; q < rowptr_u[u + 1]; ++q) {
@@ -131,34 +123,15 @@ int main() {
         HIP_OK(hipDeviceSynchronize());
         double loss_gpu;
         HIP_OK(hipMemcpy(&loss_gpu, d_loss, 8, hipMemcpyDeviceToHost));
-        // reference: delta_k = -2 (a_k - p_k), gU[u] += delta_k V[j], gV[j] += delta_k U[u], all from the pre-update tables
-        std::vector<double> gU((size_t)m * r, 0.0), gV((size_t)n * r, 0.0);
-        double loss_ref = 0;
-        for (int64_t q = 0; q < nnz; ++q) {
-            const int u = user_of[q], j = col_u[q];
-            double p = 0;
-            for (int c = 0; c < r; ++c) p += Ur[(size_t)u * ld + c] * Vr[(size_t)j * ld + c];
-            const double e = val_u[q] - p, d = -2 * e;
-            loss_ref += e * e;
-            for (int c = 0; c < r; ++c) { gU[(size_t)u * r + c] += d * Vr[(size_t)j * ld + c]; gV[(size_t)j * r + c] += d * Ur[(size_t)u * ld + c]; }
-        }
+        // reference (host_ref.h): delta_k = -2 (a_k - p_k), gU[u] += delta_k V[j], gV[j] += delta_k U[u], all from the pre-update tables
+        std::vector<double> gU, gV;
+        const double loss_ref = host_ref::mse_epoch(P, Ur, Vr, &gU, &gV);
         worst_loss = std::max(worst_loss, fabs(loss_gpu - loss_ref) / loss_ref);
         const auto Un = host_copy(d_Un, U.size()), Vn = host_copy(d_Vn, V.size());
-        auto check = [&](const std::vector<float>& Wn, std::vector<double>& Wr, const std::vector<double>& g, int rows) {
-            double gmax = 0;
-            for (double x : g) gmax = std::max(gmax, fabs(x));
-            for (int i = 0; i < rows; ++i)
-                for (int c = 0; c < r; ++c) {
-                    const double gi = g[(size_t)i * r + c];
-                    const float want = adam_fresh((float)Wr[(size_t)i * ld + c], (float)gi, adam);
-                    // the step is a near-sign function of g: compare only where g is well away from 0, then continue from the
-                    // GPU's value so that the two trajectories stay on the same tables
-                    if (fabs(gi) > 1e-3 * gmax) worst_step = std::max(worst_step, (double)fabsf(Wn[(size_t)i * ld + c] - want));
-                    Wr[(size_t)i * ld + c] = Wn[(size_t)i * ld + c];
-                }
-        };
-        check(Un, Ur, gU, m);
-        check(Vn, Vr, gV, n);
+        // the step is a near-sign function of g: compared only where g is well away from 0; the restatement then continues from the
+        // GPU's values so that the two trajectories stay on the same tables (host_ref::check_step)
+        worst_step = std::max(worst_step, host_ref::check_step(Un, Ur, gU, m, r, ld, ref_adam(adam)));
+        worst_step = std::max(worst_step, host_ref::check_step(Vn, Vr, gV, n, r, ld, ref_adam(adam)));
         std::swap(d_U, d_Un);
         std::swap(d_V, d_Vn);
     }
@@ -173,20 +146,7 @@ int main() {
     HIP_OK(hipDeviceSynchronize());
     const auto top = host_copy(d_top, (size_t)m * k);
     const auto topv = host_copy(d_topv, (size_t)m * k);
-    int wrong = 0;
-    for (int u = 0; u < m; ++u) {
-        std::vector<double> sc(n);
-        for (int j = 0; j < n; ++j) { double p = 0; for (int c = 0; c < r; ++c) p += Ur[(size_t)u * ld + c] * Vr[(size_t)j * ld + c]; sc[j] = p; }
-        std::vector<char> taken(n, 0);
-        for (int t = 0; t < k; ++t) {
-            const int j = top[(size_t)u * k + t];
-            wrong += j < 0 || j >= n || taken[j] || fabs(topv[(size_t)u * k + t] - sc[j]) > 1e-5;
-            if (j >= 0 && j < n) taken[j] = 1;
-            wrong += t > 0 && topv[(size_t)u * k + t] > topv[(size_t)u * k + t - 1];       // descending
-        }
-        const double kth = topv[(size_t)u * k + k - 1];
-        for (int j = 0; j < n; ++j) wrong += !taken[j] && sc[j] > kth + 1e-5;              // nothing better was left out
-    }
+    const int wrong = host_ref::topk_violations(top, topv, Ur, Vr, m, n, r, ld, k);
     printf("top-%d of %d users over %d items: %d violations\n", k, m, n, wrong);
     if (wrong) { fprintf(stderr, "FAIL top-k\n"); return 12; }
 
@@ -194,15 +154,7 @@ int main() {
     {
         const int S = 16, ns = 3, C = 2, wepochs = 3;
         const float wlr = 1e-3f, cc = (float)n / (float)S;
-        std::vector<int32_t> R((size_t)m * S);
-        for (int u = 0; u < m; ++u) {       // S distinct items per user (utils.py:20 draws without replacement)
-            std::set<int> pick;
-            while ((int)pick.size() < S) pick.insert(rng.next() % n);
-            int t = 0;
-            std::vector<int> v(pick.begin(), pick.end());
-            for (int q = S - 1; q > 0; --q) std::swap(v[q], v[rng.next() % (q + 1)]);     // any order: the engine sorts its copy
-            for (int j : v) R[(size_t)u * S + t++] = j;
-        }
+        const std::vector<int32_t> R = host_ref::draw_negatives(rng, m, n, S);   // any order inside a row: the engine sorts its copy
         int32_t *d_R = dev_copy(R), *d_Rs, *d_off, *d_poff, *d_ent_row, *d_ent_id;
         int64_t* d_rowptr_e;
         const int64_t E = nnz + (int64_t)m * S;
@@ -247,45 +199,13 @@ int main() {
             HIP_OK(hipDeviceSynchronize());
             double loss_gpu;
             HIP_OK(hipMemcpy(&loss_gpu, d_loss, 8, hipMemcpyDeviceToHost));
-            // reference (every stored value is > 0 here, so every interaction is a positive)
-            std::vector<double> gU((size_t)m * r, 0.0), gV((size_t)n * r, 0.0);
-            double loss_ref = 0;
-            for (int u = 0; u < m; ++u) {
-                std::vector<double> sps(S), Dd(S, 0.0);
-                for (int t = 0; t < S; ++t) { double p = 0; const int j = Rs[(size_t)u * S + t]; for (int c = 0; c < r; ++c) p += Uw[(size_t)u * ld + c] * Vw[(size_t)j * ld + c]; sps[t] = p; }
-                for (int64_t q = rowptr_u[u]; q < rowptr_u[u + 1]; ++q) {
-                    const int j = col_u[q];
-                    double p = 0;
-                    for (int c = 0; c < r; ++c) p += Uw[(size_t)u * ld + c] * Vw[(size_t)j * ld + c];
-                    double M = 0;
-                    int cnt = 0;
-                    for (int t = 0; t < S; ++t) { const double x = 1.0 - p + sps[t]; if (x >= 0) { M += x; ++cnt; } }
-                    M *= cc;
-                    loss_ref += log1p(M);
-                    const double w = cc / (1.0 + M), dk = -w * cnt;
-                    for (int t = 0; t < S; ++t) if (1.0 - p + sps[t] >= 0) Dd[t] += w;
-                    for (int c = 0; c < r; ++c) { gU[(size_t)u * r + c] += dk * Vw[(size_t)j * ld + c]; gV[(size_t)j * r + c] += dk * Uw[(size_t)u * ld + c]; }
-                }
-                for (int t = 0; t < S; ++t) {
-                    const int j = Rs[(size_t)u * S + t];
-                    for (int c = 0; c < r; ++c) { gU[(size_t)u * r + c] += Dd[t] * Vw[(size_t)j * ld + c]; gV[(size_t)j * r + c] += Dd[t] * Uw[(size_t)u * ld + c]; }
-                }
-            }
+            // reference (host_ref.h; every stored value is > 0 here, so every interaction is a positive)
+            std::vector<double> gU, gV;
+            const double loss_ref = host_ref::wmrb_epoch(P, Rs, S, cc, Uw, Vw, &gU, &gV);
             wl = std::max(wl, fabs(loss_gpu - loss_ref) / loss_ref);
             const auto Un = host_copy(d_Un, U.size()), Vn = host_copy(d_Vn, V.size());
-            auto check = [&](const std::vector<float>& Wn, std::vector<double>& Wr, const std::vector<double>& g, int rows) {
-                double gmax = 0;
-                for (double x : g) gmax = std::max(gmax, fabs(x));
-                for (int i = 0; i < rows; ++i)
-                    for (int c = 0; c < r; ++c) {
-                        const double gi = g[(size_t)i * r + c];
-                        const float want = adam_fresh((float)Wr[(size_t)i * ld + c], (float)gi, wadam);
-                        if (fabs(gi) > 1e-3 * gmax) wst = std::max(wst, (double)fabsf(Wn[(size_t)i * ld + c] - want));
-                        Wr[(size_t)i * ld + c] = Wn[(size_t)i * ld + c];
-                    }
-            };
-            check(Un, Uw, gU, m);
-            check(Vn, Vw, gV, n);
+            wst = std::max(wst, host_ref::check_step(Un, Uw, gU, m, r, ld, ref_adam(wadam)));
+            wst = std::max(wst, host_ref::check_step(Vn, Vw, gV, n, r, ld, ref_adam(wadam)));
             std::swap(d_U, d_Un);
             std::swap(d_V, d_Vn);
         }

@@ -104,8 +104,10 @@ def test_rows_with_k_or_more_infinite_scores_keep_valid_ids(ops, arith):
     g = torch.Generator().manual_seed(9)
     U, V = torch.randn(m, r, generator=g) * 0.1, torch.randn(n, r, generator=g) * 0.1
     hot = torch.arange(0, 400, 13)                      # 31 items in the first 1/64 of the catalog, on 31 different lanes ...
-    V[hot, 0] = 3.0e38
-    U[:50, 0] = 3.0e38                                  # ... whose score with users 0..49 overflows to +inf
+    # 2^127 is one bf16 plane (the other two are 0), so the plane kernel's products overflow to +inf like the fp32 kernel's; a value
+    # with a NEGATIVE low plane (3.0e38 rounds up in bf16) gives +inf - inf = NaN there: such scores are not ranked (_ops.predict_topk)
+    V[hot, 0] = 2.0 ** 127
+    U[:50, 0] = 2.0 ** 127                              # ... whose score with users 0..49 overflows to +inf
     U[:50, 1:] = 0
     V[hot, 1:] = 0
     vals, idx = ops.predict_topk(U, V, k, return_values=True, arithmetic=arith)
