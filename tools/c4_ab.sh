@@ -5,5 +5,5 @@ for c in $1; do
   python -c "
 import json,sys
 d=json.loads(open('gpurun_out/c4ab.json').read().strip().splitlines()[-1])
-print('$c', round(d['ms_per_step'],2), {k['kernel'][5:]:round(k['ms'],2) for k in d['roofline']['kernels']}, flush=True)"
+print('$c', round(d['ms_per_step'],2), {k[5:]:v[0] for k,v in d['roofline']['kernels_ms'].items()}, flush=True)"
 done

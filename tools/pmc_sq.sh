@@ -35,3 +35,4 @@ for k, d in sorted(summary.items(), key=lambda kv: -kv[1].get('SQ_BUSY_CU_CYCLES
     print(k)
     print('   ' + '  '.join(f'{c}={v:.4g}' for c, v in sorted(d.items())))
 PY
+rm -rf $OUT/p[0-9]   # raw per-dispatch CSVs: tens of MB per pass (gpurun copies back at most 64 MiB)

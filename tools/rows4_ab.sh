@@ -9,5 +9,5 @@ for c in $2; do
   python -c "
 import json,sys
 d=json.loads(open('gpurun_out/r4_${r4}_${uc:-d}_${lag:-1}.json').read().strip().splitlines()[-1])
-print('$c', round(d['ms_per_step'],1), {k['kernel'][5:]:round(k['ms'],1) for k in d['roofline']['kernels']}, flush=True)"
+print('$c', round(d['ms_per_step'],1), {k[5:]:round(v[0],1) for k,v in d['roofline']['kernels_ms'].items()}, flush=True)"
 done
