@@ -207,6 +207,26 @@ int tmf_wmrb_scores3_f32(const tmf_slice_lists* lists, const void* U, const void
                          int n_components, void* stream);
 int tmf_wmrb_scores3_bf16(const tmf_slice_lists* lists, const void* U, const void* V, float* sp, float* p,
                           int n_components, void* stream);
+/* Row-stationary form of scores3 (speed only - the same sp / p up to the order of the fp32 sum inside a dot product; exact on
+ * dyadic data): for catalogs far beyond the L2s, where a (user, slice) visit holds a handful of rows and scores3 is bound by what
+ * every visit reads besides them (matrix_factorization.py:153-154 and utils.py:94-105 are what both compute).  A workgroup owns
+ * tmf_wmrb_scores5_users_per_workgroup() consecutive users, keeps their rows in LDS and walks ONE flat stream of its (user, item)
+ * pairs - negatives and interactions alike, ordered by item (slice) so that all workgroups of a launch gather from the same
+ * cache-sized window of V at any time:
+ *   ids [E8]     (local user << 24) | item            (E8 = every workgroup's entries padded to a multiple of 8)
+ *   outs [E8]    >= 0: index into sp ([n_users, n_samples] flat); < 0: ~index into p ([nnz]); INT32_MIN: padding entry
+ *   wg_ptr [n_wg + 1]  first entry of every workgroup's stream (multiples of 8), n_wg = ceil(n_users / users_per_workgroup)
+ * wgs_per_launch <= 0: one workgroup per CU (all workgroups of a launch resident, walking the catalog at the same pace).
+ * Needs rows of 32 lanes (fp32 65..128, bf16 129..256 components), n_items < 2^24 and a V table below 4 GB:
+ * tmf_wmrb_scores5_supported(). */
+int tmf_wmrb_scores5_users_per_workgroup(void);
+int tmf_wmrb_scores5_supported(int n_components, int bf16, int64_t n_items);
+int tmf_wmrb_scores5_f32(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg, int64_t n_users,
+                         int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
+                         int wgs_per_launch, void* stream);
+int tmf_wmrb_scores5_bf16(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg, int64_t n_users,
+                          int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
+                          int wgs_per_launch, void* stream);
 int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
                     int32_t n_samples, float c, float* delta, float* D, float* loss_part, void* stream);
 /* The same with the order in which the waves take the users (a permutation of 0 .. n_users - 1, or NULL = 0, 1, 2 ...): a user

@@ -420,6 +420,7 @@ class WmrbPlan:
         self.hinge_order = hinge_user_order(plan.rowptr_u)
         self.D = self.wbuf[nnz:].view(m, S)
         self._lists = None
+        self.s5 = None   # Scores5Plan, built by the TrainState that wants the row-stationary scores kernel (scores5_wanted)
 
     def lists(self, plan):
         """tmf_slice_lists of the sliced pass (kept alive with the plan)."""
@@ -445,6 +446,88 @@ class WmrbPlan:
         out = torch.empty_like(self.D)
         out.scatter_(1, perm, self.D)
         return out
+
+
+def scores5_wanted(plan, wplan, n_components, dtype=torch.float32):
+    """Whether the sliced user pass computes its scores with the row-stationary kernel (tmf_wmrb_scores5: workgroups own 256
+    users, keep their rows in LDS and walk one flat stream of (user, item) pairs ordered by item) instead of tmf_wmrb_scores3.
+    It pays where a catalog is so large that an L2-sized slice leaves a (user, slice) visit of scores3 only a few rows
+    (config 5: 1M items x 512 bytes = 128 slices of 4 MB, 9 rows per visit: 63 -> ~40 ms) and loses where visits are long
+    (C4: 13 slices, 86 rows).  TMF_SCORES5 = 0 | 1 forces it where the kernel exists (rows of 32 lanes, < 2^24 items, table < 4 GB)."""
+    env = os.environ.get('TMF_SCORES5')
+    if env == '0' or wplan is None or not wplan.sliced or not plan.col_u.is_cuda:
+        return False
+    bf16 = dtype is torch.bfloat16
+    if not _lib.load_library().tmf_wmrb_scores5_supported(int(n_components), int(bf16), int(plan.n_items)):
+        return False
+    if env == '1':
+        return True
+    row_bytes = _lib.padded_ld(n_components, dtype) * (2 if bf16 else 4)
+    l2_slices = max(1.0, plan.n_items * row_bytes / float(4 << 20))
+    rows_per_visit = (wplan.S + plan.nnz / max(plan.n_users, 1)) / l2_slices
+    return rows_per_visit < 24.0
+
+
+class Scores5Plan:
+    """Entry streams of tmf_wmrb_scores5 (include/tmf.h), built once per fit from the sliced plan: every (user, item) pair whose
+    score the epoch needs - interaction k of the CSR (score -> p[k]) and negative (u, pos) of the item-sorted table (score ->
+    sp[u, pos]) - keyed by (workgroup = u // 256, slice = item // width) and put in that order by ONE stable radix sort
+    (stable_order): inside a (workgroup, slice) chunk the interactions come first, then the negatives, each by user and item.
+    The slices only order the stream (the kernel never sees them), so they are fine: ~512 KB of V rows each."""
+
+    PAD = -2 ** 31
+
+    def __init__(self, plan, wplan, n_components, dtype=torch.float32, slice_bytes=None):
+        lib = _lib.get()
+        dev = plan.col_u.device
+        UB = int(lib.tmf_wmrb_scores5_users_per_workgroup())
+        m, S = wplan.R.shape
+        nnz, n = plan.nnz, plan.n_items
+        E = nnz + m * S
+        self.n_wg = n_wg = -(-m // UB)
+        row_bytes = _lib.padded_ld(n_components, dtype) * (2 if dtype is torch.bfloat16 else 4)
+        slice_bytes = int(os.environ.get('TMF_S5_SLICE_BYTES', slice_bytes or (512 << 10)))
+        ns = int(min(max(1, -(-n * row_bytes // slice_bytes)), 4096, max(1, (2 ** 31 - 1) // max(n_wg, 1))))
+        width = -(-n // ns)
+        self.n_slices = ns
+        i32 = torch.int32
+        uo = plan.user_of                                                  # int32 [nnz]
+        rows = torch.arange(m, device=dev, dtype=i32)
+        keys = torch.empty(E, dtype=i32, device=dev)
+        keys[:nnz] = (uo // UB) * ns + plan.col_u // width
+        keys[nnz:].view(m, S).copy_(((rows // UB) * ns)[:, None] + wplan.R // width)
+        perm, rowptr = stable_order(keys, n_wg * ns)
+        del keys
+        packed = torch.empty(E, dtype=i32, device=dev)
+        packed[:nnz] = ((uo % UB) << 24) | plan.col_u
+        packed[nnz:].view(m, S).copy_(((rows % UB) << 24)[:, None] | wplan.R)
+        ids_sorted = packed[perm]
+        del packed
+        outs = torch.empty(E, dtype=i32, device=dev)
+        outs[:nnz] = -1 - torch.arange(nnz, device=dev, dtype=i32)         # ~k: the score of interaction k goes to p[k]
+        outs[nnz:] = torch.arange(m * S, device=dev, dtype=i32)            # u * S + pos: to sp[u, pos]
+        outs_sorted = outs[perm]
+        del outs, perm
+        # every workgroup's stream padded to whole steps of 8 with its last entry's id (a valid user, a resident row) and PAD
+        wg_ptr = rowptr[::ns].contiguous()                                  # [n_wg + 1]
+        cnt = wg_ptr[1:] - wg_ptr[:-1]
+        wg_ptr8 = _excl_cumsum((cnt + 7) // 8 * 8)
+        E8 = int(wg_ptr8[-1])
+        self.ids = torch.empty(E8 + 8, dtype=i32, device=dev)
+        self.outs = torch.full((E8 + 8,), self.PAD, dtype=i32, device=dev)
+        self.ids[E8:] = 0
+        step = 1 << 27
+        for q0 in range(0, E8, step):
+            q = torch.arange(q0, min(q0 + step, E8), device=dev, dtype=torch.int64)
+            wg = torch.searchsorted(wg_ptr8, q, right=True) - 1
+            r = q - wg_ptr8[wg]
+            c = cnt[wg]
+            src = wg_ptr[wg] + torch.minimum(r, c - 1)
+            self.ids[q0:q0 + q.numel()] = ids_sorted[src]
+            self.outs[q0:q0 + q.numel()] = torch.where(r < c, outs_sorted[src], torch.full_like(src, self.PAD).to(i32))
+            del q, wg, r, c, src
+        self.wg_ptr = wg_ptr8
+        self.n_entries, self.n_padded = E, E8
 
 
 class TrainState:
@@ -491,6 +574,8 @@ class TrainState:
             else:
                 self.part_layers, self.gradu_launches = 1, 1           # a launch per slice
             need.update(sp=m * S, pk=max(plan.nnz, 1), part=self.part_layers * max(m, 1) * self.ld)
+            if getattr(wplan, 's5', None) is None and wplan.seg_e is not None and scores5_wanted(plan, wplan, self.r, dtype):
+                wplan.s5 = Scores5Plan(plan, wplan, self.r, dtype)
         if wplan is not None and wplan.rows4:
             L = _lib.load_library()
             per_group = L.tmf_wsum_rows4_rows_per_group(self.r, int(dtype is torch.bfloat16))
@@ -612,8 +697,15 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None, user_epi=_lib.EPI_ADAM, 
         _lib.check(rc_fn(), lib)
         if prof:
             prof.stop(name)
-    timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores3' + st.sfx)(lists, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp),
-                                                                            _lib.ptr(st.pk), r, s))
+    s5 = getattr(w, 's5', None)
+    if s5 is not None:
+        # row-stationary scores: workgroups own 256 users (rows in LDS) and walk one flat stream of (user, item) pairs
+        timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores5' + st.sfx)(
+            _lib.ptr(s5.ids), _lib.ptr(s5.outs), _lib.ptr(s5.wg_ptr), s5.n_wg, m, p.n_items, _lib.ptr(st.U), _lib.ptr(st.V),
+            _lib.ptr(st.sp), _lib.ptr(st.pk), r, int(os.environ.get('TMF_S5_WGS', 0)), s))
+    else:
+        timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores3' + st.sfx)(lists, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp),
+                                                                                _lib.ptr(st.pk), r, s))
     timed('wmrb_hinge', lambda: lib.tmf_wmrb_hinge2_ordered(_lib.ptr(p.rowptr_u), _lib.ptr(p.val_u), _lib.ptr(st.pk), _lib.ptr(st.sp),
                                                             i32(m), i32(S), c, _lib.ptr(w.delta), _lib.ptr(w.D), _lib.ptr(st.loss_part),
                                                             _lib.ptr(w.hinge_order), s))

@@ -258,6 +258,98 @@ __device__ __forceinline__ void to_frag(Frag<NV>& f, const Raw<NV, __bf16>& r) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Helpers of the row-stationary scores kernel (k_wmrb_scores5, tmf_wmrb.hip): rows addressed with 32-bit byte offsets from a
+// wave-uniform base, dot products on packed pairs, eight scores reduced at once.
+// ---------------------------------------------------------------------------------------------
+typedef float tmf_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int G, int NV, typename T>
+struct RowBytes {
+    static constexpr uint32_t value = 4u * G * NV * (uint32_t)sizeof(T);
+};
+
+// row * row_bytes + lane_off in ONE instruction (row_bytes is a power of two and lane_off < row_bytes, so the sum is an OR; the
+// compiler's own choice for the same expression is v_lshlrev_b32 + v_or_b32)
+template <uint32_t ROW_BYTES>
+__device__ __forceinline__ uint32_t row_byte_off(uint32_t row, uint32_t lane_off) {
+    static_assert((ROW_BYTES & (ROW_BYTES - 1)) == 0, "rows are a power of two bytes long");
+    uint32_t off;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(row), "n"(__builtin_ctz(ROW_BYTES)), "v"(lane_off));
+    return off;
+}
+
+// Row `row` of a table of fewer than 2^32 bytes whose base is wave-uniform: global_load ... v_off, s[base:base+1]
+template <int G, int NV>
+__device__ __forceinline__ void load_raw32(Raw<NV, float>& r, const float* __restrict__ T, uint32_t row, uint32_t lane_off) {
+    const char* p = reinterpret_cast<const char*>(T) + row_byte_off<RowBytes<G, NV, float>::value>(row, lane_off);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) r.v[v] = *reinterpret_cast<const float4*>(p + 16 * G * v);
+}
+template <int G, int NV>
+__device__ __forceinline__ void load_raw32(Raw<NV, __bf16>& r, const __bf16* __restrict__ T, uint32_t row, uint32_t lane_off) {
+    const char* p = reinterpret_cast<const char*>(T) + row_byte_off<RowBytes<G, NV, __bf16>::value>(row, lane_off);
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv) r.v[pv] = *reinterpret_cast<const bf16x8*>(p + 16 * G * pv);
+}
+
+// This lane's share of <x, y>, both rows as loaded (Raw).  fp32: two independent chains on the (x, y) and (z, w) pairs, added at
+// the end (v_pk_mul / v_pk_fma / v_pk_add); bf16: v_dot2c_f32_bf16 - exact products, fp32 accumulation, no conversions.
+// Another summation order than dot_partial: the two agree to rounding, not to the bit (and exactly on dyadic data).
+template <int NV>
+__device__ __forceinline__ float dot_raw(const Raw<NV, float>& x, const Raw<NV, float>& y) {
+    tmf_f2 a = tmf_f2{x.v[0].x, x.v[0].y} * tmf_f2{y.v[0].x, y.v[0].y};
+    a = __builtin_elementwise_fma(tmf_f2{x.v[0].z, x.v[0].w}, tmf_f2{y.v[0].z, y.v[0].w}, a);
+#pragma unroll
+    for (int v = 1; v < NV; ++v) {
+        a = __builtin_elementwise_fma(tmf_f2{x.v[v].x, x.v[v].y}, tmf_f2{y.v[v].x, y.v[v].y}, a);
+        a = __builtin_elementwise_fma(tmf_f2{x.v[v].z, x.v[v].w}, tmf_f2{y.v[v].z, y.v[v].w}, a);
+    }
+    return a.x + a.y;
+}
+template <int NV>
+__device__ __forceinline__ float dot_raw(const Raw<NV, __bf16>& x, const Raw<NV, __bf16>& y) {
+    float s = 0.f;
+#pragma unroll
+    for (int pv = 0; pv < NV / 2; ++pv)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{x.v[pv][2 * i], x.v[pv][2 * i + 1]}, bf16x2{y.v[pv][2 * i], y.v[pv][2 * i + 1]}, s, false);
+    return s;
+}
+
+#define TMF_DPP_MOV(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
+
+// Eight per-lane partial sums p[0..7] (eight gathered rows) -> their eight sums over a 32-lane group, TRANSPOSED: afterwards lane l
+// holds the complete sum of entry entry_of_lane(l) (every entry on 4 lanes).  v_permlane16_swap exchanges halves of two registers
+// (one add then finishes the xor-16 level for BOTH entries), row_ror:8 is a true xor-8 butterfly followed by a select; only the
+// quad levels run on a register that already holds four entries: 25 instructions per 8 sums instead of 8 x 7.
+// A fixed summation tree, so results are bit-reproducible; every lane that holds entry e holds the same bits.
+struct Reduce8x32 {
+    static __device__ __forceinline__ int entry_of_lane(int lane) { return ((lane >> 4) & 1) | ((lane >> 2) & 2) | (lane & 4); }
+    static __device__ __forceinline__ bool owner(int lane) { return (lane & 3) == 0; }
+    static __device__ __forceinline__ float run(const float (&p)[8], int lane) {
+        float q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // xor 16: lanes with bit 4 clear keep p[2i], the others p[2i + 1]
+            const auto s = __builtin_amdgcn_permlane16_swap(__float_as_int(p[2 * i]), __float_as_int(p[2 * i + 1]), false, false);
+            q[i] = __int_as_float(s[0]) + __int_as_float(s[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] += TMF_DPP_MOV(q[i], 0x128);   // row_ror:8 = xor 8
+        const bool b3 = lane & 8, b2 = lane & 4;
+        float r0 = b3 ? q[1] : q[0], r1 = b3 ? q[3] : q[2];
+        r0 += TMF_DPP_MOV(r0, 0xB1);    // quad_perm [1,0,3,2]
+        r1 += TMF_DPP_MOV(r1, 0xB1);
+        r0 += TMF_DPP_MOV(r0, 0x4E);    // quad_perm [2,3,0,1]
+        r1 += TMF_DPP_MOV(r1, 0x4E);
+        r0 += TMF_DPP_MOV(r0, 0x141);   // row_half_mirror (quads are uniform by now)
+        r1 += TMF_DPP_MOV(r1, 0x141);
+        return b2 ? r1 : r0;
+    }
+};
+
 // Row stores.  Every row this engine writes (new table rows, slab partials, raw gradients, per-slice partials) is written
 // once and read by a LATER kernel, so the stores carry the non-temporal hint.  Measured on one box, same run: the hint
 // itself changes nothing (item pass at C4 36.8 ms without, 36.6 ms with); what took that kernel from 44.0 to 36.8 ms was

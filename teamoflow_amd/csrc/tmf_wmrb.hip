@@ -1000,6 +1000,129 @@ static int wmrb_gradu4_impl(const tmf_slice_lists* lists, const float* D, const 
     return check_launch("tmf_wmrb_gradu4");
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Row-stationary scores ("scores5", round 4).  Built for catalogs far beyond the L2s (config 5: V = 512 MB), where a slice
+// small enough for an L2 leaves a (user, slice) visit a handful of rows and k_wmrb_scores3 pays for every visit with the
+// user's own row (512 bytes from HBM), two offsets and a 17-byte piece of the id list - it ends up bound by the fabric at
+// 34 x its compulsory traffic (profiles/r03_c5_pmc.json).  Here a workgroup OWNS `UB` users, keeps their rows in LDS for the
+// whole launch (UB x row bytes: 128 KB of the CU's 160) and walks ONE flat stream of entries prepared once per fit
+// (_engine.Scores5Plan): all (user, item) pairs of its users - negatives and interactions alike - ordered by item slice,
+// eight per step, each a packed (local user << 24 | item) id and the place its score goes to.  No offsets, no per-visit
+// reads, no user row from memory after the first: what is left is the row gathers themselves - and since every workgroup of
+// a launch walks the catalog front to back at the same pace, the rows they gather at any moment come from a window of a
+// few MB that the L2s hold.  A launch covers as many workgroups as are resident together (one per CU); the host launches
+// generation after generation.
+//   step = 8 consecutive entries of the workgroup's stream; lane group gid takes steps gid, gid + NGB, ...
+//   ids   : the 8 ids of a step in two 16-byte loads that every lane of the group issues to the same address (one request),
+//           fetched one step ahead of their use
+//   x     : the entry's user row from LDS (ds_read_b128, conflict-free: 32 lanes x 16 bytes = the row)
+//   score : dot_raw + Reduce8x32 (tmf_common.h); the four lanes that end up with entry e hold its score, one of them stores
+//           it where out[] says: >= 0 -> sp[out], < 0 -> p[~out], INT_MIN -> a padding entry (the stream of a workgroup is
+//           padded to whole steps with a valid row id)
+// Scores agree with k_wmrb_scores3 to rounding (another summation tree), exactly on dyadic data.
+// ---------------------------------------------------------------------------------------------
+namespace tmf {
+constexpr int kS5Users = 256;        // users per workgroup (8-bit local user in the packed id)
+constexpr int kS5Waves = 16;         // one workgroup per CU: 4 waves per SIMD
+constexpr int kS5Pad = INT32_MIN;    // out[] of a padding entry
+
+template <int NV, typename T>
+__global__ __launch_bounds__(64 * kS5Waves) void k_wmrb_scores5(const int32_t* __restrict__ ids, const int32_t* __restrict__ outs,
+                                                               const int64_t* __restrict__ wg_ptr, int64_t wg0, int64_t n_users,
+                                                               const T* __restrict__ U, const T* __restrict__ V,
+                                                               float* __restrict__ sp, float* __restrict__ p) {
+    constexpr int G = 32, NGB = 2 * kS5Waves;
+    constexpr uint32_t RB = RowBytes<G, NV, T>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [kS5Users] rows as stored
+    const int tid = threadIdx.x, lane = tid & 63, g = lane & (G - 1), gid = tid / G;
+    const int64_t wg = wg0 + blockIdx.x;
+    const int64_t ubeg = wg * kS5Users;
+    const int nu = (int)((n_users - ubeg < kS5Users) ? n_users - ubeg : kS5Users);
+    // the workgroup's rows -> LDS, 16 bytes per lane (rows of U are contiguous: one flat copy)
+    {
+        const tmf_f4* src = reinterpret_cast<const tmf_f4*>(reinterpret_cast<const char*>(U) + ubeg * (int64_t)RB);
+        tmf_f4* dst = reinterpret_cast<tmf_f4*>(smem_raw);
+        for (int i = tid; i < nu * (int)(RB / 16); i += 64 * kS5Waves) dst[i] = __builtin_nontemporal_load(src + i);
+    }
+    __syncthreads();
+    const int64_t beg = wg_ptr[wg], end = wg_ptr[wg + 1];   // multiples of 8 (padded)
+    const int64_t steps = (end - beg) >> 3;
+    const uint32_t loff = 16u * (uint32_t)g;
+    const int my_entry = Reduce8x32::entry_of_lane(lane);
+    const bool owner = Reduce8x32::owner(lane);
+    const int4* id4 = reinterpret_cast<const int4*>(ids + beg);   // 32-byte aligned steps
+    int64_t st = gid;
+    int4 na = make_int4(0, 0, 0, 0), nb = na;
+    int no = kS5Pad;
+    if (st < steps) {
+        na = id4[2 * st];
+        nb = id4[2 * st + 1];
+        no = outs[beg + 8 * st + my_entry];
+    }
+    while (st < steps) {
+        const int4 ia = na, ib = nb;
+        const int o = no;
+        const int64_t nx = st + NGB;
+        if (nx < steps) {   // the next step's ids and places, in flight while this step's rows are gathered
+            na = id4[2 * nx];
+            nb = id4[2 * nx + 1];
+            no = outs[beg + 8 * nx + my_entry];
+        }
+        const int idv[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        Raw<NV, T> y[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) load_raw32<G, NV>(y[t], V, (uint32_t)idv[t] & 0xffffffu, loff);
+        float pr[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            Raw<NV, T> x;   // the entry's user row, from LDS
+            const char* xr = smem_raw + ((uint32_t)idv[t] >> 24) * RB + loff;
+            if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) x.v[v] = *reinterpret_cast<const float4*>(xr + 16 * G * v);
+            } else {
+#pragma unroll
+                for (int pv = 0; pv < NV / 2; ++pv) x.v[pv] = *reinterpret_cast<const bf16x8*>(xr + 16 * G * pv);
+            }
+            pr[t] = dot_raw<NV>(x, y[t]);
+        }
+        const float sc = Reduce8x32::run(pr, lane);
+        if (owner && o != kS5Pad) __builtin_nontemporal_store(sc, o >= 0 ? sp + o : p + ~o);
+        st = nx;
+    }
+}
+
+}  // namespace tmf
+
+template <typename T>
+static int wmrb_scores5_impl(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg, int64_t n_users,
+                             int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
+                             int wgs_per_launch, void* stream) {
+    if (n_wg == 0 || n_users == 0) return TMF_OK;
+    const RowGeom geom = row_geom_of<T>(n_components);
+    TMF_REQUIRE(ids && outs && wg_ptr && U && V && sp && p, "wmrb_scores5: null pointer");
+    TMF_REQUIRE(n_wg == (n_users + kS5Users - 1) / kS5Users, "wmrb_scores5: %lld workgroups for %lld users (%d per workgroup)",
+                (long long)n_wg, (long long)n_users, kS5Users);
+    const size_t row_bytes = (size_t)geom.ld * sizeof(T);
+    if (geom.G != 32 || row_bytes * kS5Users > 128 * 1024 || n_items <= 0 || n_items >= (1 << 24) ||
+        (int64_t)n_items * (int64_t)row_bytes >= ((int64_t)1 << 32)) {
+        set_error("wmrb_scores5: needs rows of 32 lanes (fp32 65..128 / bf16 129..256 components) and fewer than 2^24 items "
+                  "in a table below 4 GB (got %d components, %lld items)", n_components, (long long)n_items);
+        return TMF_E_UNSUPPORTED;
+    }
+    if (wgs_per_launch <= 0) {   // one workgroup per CU: every workgroup of a launch resident, all walking the catalog together
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        wgs_per_launch = cus > 0 ? cus : 256;
+    }
+    const size_t lds = row_bytes * kS5Users;
+#define CALL(G_, NV_)                                                                                                           {                                                                                                                               if constexpr (G_ == 32) {                                                                                                       static LdsGrant grant;                                                                                                      if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_wmrb_scores5<NV_, T>), lds, grant)) return rc;              for (int64_t w0 = 0; w0 < n_wg; w0 += wgs_per_launch) {                                                                         const unsigned blocks = (unsigned)((n_wg - w0 < wgs_per_launch) ? n_wg - w0 : wgs_per_launch);                              hipLaunchKernelGGL((k_wmrb_scores5<NV_, T>), dim3(blocks), dim3(64 * kS5Waves), lds, (hipStream_t)stream, ids,                                    outs, wg_ptr, w0, n_users, (const T*)U, (const T*)V, sp, p);                                         }                                                                                                                       }                                                                                                                       }
+    TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    return check_launch("tmf_wmrb_scores5");
+}
+
 template <typename T>
 static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users, const void* U_old, void* U_out,
                             int n_components, int epi, tmf_adam adam, void* stream) {
@@ -1024,6 +1147,12 @@ static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users
                                           int n_components, void* stream) {                                               \
         return wmrb_scores3_impl<T_>(lists, U, V, sp, p, n_components, stream);                                           \
     }                                                                                                                     \
+    extern "C" int tmf_wmrb_scores5_##SFX(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg,    \
+                                          int64_t n_users, int64_t n_items, const void* U, const void* V, float* sp,      \
+                                          float* p, int n_components, int wgs_per_launch, void* stream) {                 \
+        return wmrb_scores5_impl<T_>(ids, outs, wg_ptr, n_wg, n_users, n_items, U, V, sp, p, n_components, wgs_per_launch, \
+                                     stream);                                                                             \
+    }                                                                                                                     \
     extern "C" int tmf_wmrb_gradu3_##SFX(const tmf_slice_lists* lists, const float* D, const float* delta,                \
                                          const void* V, float* part, int per_slice_launches, int n_components,            \
                                          void* stream) {                                                                  \
@@ -1042,3 +1171,11 @@ static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users
 
 TMF_SLICED_ENTRY_POINTS(f32, float)
 TMF_SLICED_ENTRY_POINTS(bf16, __bf16)
+
+extern "C" int tmf_wmrb_scores5_users_per_workgroup(void) { return tmf::kS5Users; }
+extern "C" int tmf_wmrb_scores5_supported(int n_components, int bf16, int64_t n_items) {
+    const tmf::RowGeom geom = bf16 ? tmf::row_geom_bf16(n_components) : tmf::row_geom(n_components);
+    const int64_t row_bytes = (int64_t)geom.ld * (bf16 ? 2 : 4);
+    return geom.G == 32 && row_bytes * tmf::kS5Users <= 128 * 1024 && n_items > 0 && n_items < (1 << 24) &&
+           n_items * row_bytes < ((int64_t)1 << 32);
+}
