@@ -217,16 +217,23 @@ int tmf_wmrb_scores3_bf16(const tmf_slice_lists* lists, const void* U, const voi
  *   outs [E8]    >= 0: index into sp ([n_users, n_samples] flat); < 0: ~index into p ([nnz]); INT32_MIN: padding entry
  *   wg_ptr [n_wg + 1]  first entry of every workgroup's stream (multiples of 8), n_wg = ceil(n_users / users_per_workgroup)
  * wgs_per_launch <= 0: one workgroup per CU (all workgroups of a launch resident, walking the catalog at the same pace).
+ * Pacing (optional, speed only): wstart [n_wg, n_windows + 1] = the first step (8 entries) of every catalog window in every
+ * workgroup's stream (wstart[., n_windows] = its steps) and a workspace of tmf_wmrb_scores5_workspace_bytes() (zeroed by the
+ * call): a workgroup then starts window w only when the workgroups sharing its XCD have completed window w - lag - 1 (bounded
+ * waits), so that the rows being gathered span lag + 1 windows.  NULL = every workgroup runs freely.
  * Needs rows of 32 lanes (fp32 65..128, bf16 129..256 components), n_items < 2^24 and a V table below 4 GB:
  * tmf_wmrb_scores5_supported(). */
 int tmf_wmrb_scores5_users_per_workgroup(void);
 int tmf_wmrb_scores5_supported(int n_components, int bf16, int64_t n_items);
+size_t tmf_wmrb_scores5_workspace_bytes(int64_t n_wg, int32_t n_windows, int wgs_per_launch);
 int tmf_wmrb_scores5_f32(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg, int64_t n_users,
                          int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
-                         int wgs_per_launch, void* stream);
+                         int wgs_per_launch, const int32_t* wstart, int32_t n_windows, int lag, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int tmf_wmrb_scores5_bf16(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg, int64_t n_users,
                           int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
-                          int wgs_per_launch, void* stream);
+                          int wgs_per_launch, const int32_t* wstart, int32_t n_windows, int lag, void* workspace,
+                          size_t workspace_bytes, void* stream);
 int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
                     int32_t n_samples, float c, float* delta, float* D, float* loss_part, void* stream);
 /* The same with the order in which the waves take the users (a permutation of 0 .. n_users - 1, or NULL = 0, 1, 2 ...): a user

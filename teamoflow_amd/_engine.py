@@ -451,21 +451,12 @@ class WmrbPlan:
 def scores5_wanted(plan, wplan, n_components, dtype=torch.float32):
     """Whether the sliced user pass computes its scores with the row-stationary kernel (tmf_wmrb_scores5: workgroups own 256
     users, keep their rows in LDS and walk one flat stream of (user, item) pairs ordered by item) instead of tmf_wmrb_scores3.
-    It pays where a catalog is so large that an L2-sized slice leaves a (user, slice) visit of scores3 only a few rows
-    (config 5: 1M items x 512 bytes = 128 slices of 4 MB, 9 rows per visit: 63 -> ~40 ms) and loses where visits are long
-    (C4: 13 slices, 86 rows).  TMF_SCORES5 = 0 | 1 forces it where the kernel exists (rows of 32 lanes, < 2^24 items, table < 4 GB)."""
-    env = os.environ.get('TMF_SCORES5')
-    if env == '0' or wplan is None or not wplan.sliced or not plan.col_u.is_cuda:
+    OPT-IN (TMF_SCORES5=1), never the default: built in round 4 for the config-5 shard (1M items x 512 bytes, 9 rows per
+    (user, slice) visit of scores3) and measured there at 68 - 124 ms against 63 ms for scores3, whatever the pacing
+    (profiles/r04_scores5_experiment.txt).  Needs rows of 32 lanes, fewer than 2^24 items and a table below 4 GB."""
+    if os.environ.get('TMF_SCORES5') != '1' or wplan is None or not wplan.sliced or not plan.col_u.is_cuda:
         return False
-    bf16 = dtype is torch.bfloat16
-    if not _lib.load_library().tmf_wmrb_scores5_supported(int(n_components), int(bf16), int(plan.n_items)):
-        return False
-    if env == '1':
-        return True
-    row_bytes = _lib.padded_ld(n_components, dtype) * (2 if bf16 else 4)
-    l2_slices = max(1.0, plan.n_items * row_bytes / float(4 << 20))
-    rows_per_visit = (wplan.S + plan.nnz / max(plan.n_users, 1)) / l2_slices
-    return rows_per_visit < 24.0
+    return bool(_lib.load_library().tmf_wmrb_scores5_supported(int(n_components), int(dtype is torch.bfloat16), int(plan.n_items)))
 
 
 class Scores5Plan:
@@ -528,6 +519,24 @@ class Scores5Plan:
             del q, wg, r, c, src
         self.wg_ptr = wg_ptr8
         self.n_entries, self.n_padded = E, E8
+        # pacing: the workgroups of a launch meet every `pace_every` slices (tmf.h: window w may start when the peers have
+        # completed window w - lag - 1; lag 0 = a barrier per window) and run freely in between - equal work per slice keeps them
+        # within a slice or two of each other over such a stretch, a rendezvous per slice would cost more than a slice takes.
+        # Window 0 is empty: passing it is the start line (every workgroup has its rows in LDS).  wstart = first step (8 entries)
+        # of every window in every workgroup's stream; the padding sits behind a workgroup's last entry, so offsets inside a
+        # workgroup are those of the sorted list
+        every = max(1, int(os.environ.get('TMF_S5_PACE_EVERY', 32)))
+        firsts = list(range(0, ns, every))
+        off = rowptr[:n_wg * ns].view(n_wg, ns)[:, firsts] - wg_ptr[:-1, None]
+        self.n_windows = nwin = len(firsts) + 1
+        self.wstart = torch.zeros(n_wg, nwin + 1, dtype=i32, device=dev)
+        self.wstart[:, 1:nwin] = ((off + 7) // 8).to(i32)
+        self.wstart[:, nwin] = ((wg_ptr8[1:] - wg_ptr8[:-1]) // 8).to(i32)
+        self.lag = int(os.environ.get('TMF_S5_LAG', 0))
+        self.wgs_per_launch = int(os.environ.get('TMF_S5_WGS', 0))
+        self.paced = os.environ.get('TMF_S5_PACE', '1') != '0' and ns > 1
+        nb = lib.tmf_wmrb_scores5_workspace_bytes(n_wg, nwin, self.wgs_per_launch) if self.paced else 0
+        self.sync = torch.zeros(max(nb // 4, 1), dtype=i32, device=dev)
 
 
 class TrainState:
@@ -702,7 +711,8 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None, user_epi=_lib.EPI_ADAM, 
         # row-stationary scores: workgroups own 256 users (rows in LDS) and walk one flat stream of (user, item) pairs
         timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores5' + st.sfx)(
             _lib.ptr(s5.ids), _lib.ptr(s5.outs), _lib.ptr(s5.wg_ptr), s5.n_wg, m, p.n_items, _lib.ptr(st.U), _lib.ptr(st.V),
-            _lib.ptr(st.sp), _lib.ptr(st.pk), r, int(os.environ.get('TMF_S5_WGS', 0)), s))
+            _lib.ptr(st.sp), _lib.ptr(st.pk), r, s5.wgs_per_launch, _lib.ptr(s5.wstart) if s5.paced else None, i32(s5.n_windows),
+            s5.lag, _lib.ptr(s5.sync) if s5.paced else None, s5.sync.numel() * 4, s))
     else:
         timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores3' + st.sfx)(lists, _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp),
                                                                                 _lib.ptr(st.pk), r, s))

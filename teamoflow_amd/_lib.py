@@ -76,7 +76,8 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_scores3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_scores5_users_per_workgroup': (_I, []),
     'tmf_wmrb_scores5_supported': (_I, [_I, _I, _L]),
-    'tmf_wmrb_scores5_f32': (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _I, _I, _P]),
+    'tmf_wmrb_scores5_workspace_bytes': (_SZ, [_L, _I32, _I]),
+    'tmf_wmrb_scores5_f32': (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _I, _I, _P, _I32, _I, _P, _SZ, _P]),
     'tmf_wmrb_hinge2': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P]),
     'tmf_wmrb_hinge2_ordered': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P]),
     'tmf_wmrb_gradu3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _I, _P]),

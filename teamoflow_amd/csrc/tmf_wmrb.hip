@@ -1024,81 +1024,197 @@ static int wmrb_gradu4_impl(const tmf_slice_lists* lists, const float* D, const 
 // ---------------------------------------------------------------------------------------------
 namespace tmf {
 constexpr int kS5Users = 256;        // users per workgroup (8-bit local user in the packed id)
-constexpr int kS5Waves = 16;         // one workgroup per CU: 4 waves per SIMD
+constexpr int kS5Waves = 15;         // worker waves (+ 1 pacer wave = 1024 threads, the largest workgroup): one workgroup per CU
 constexpr int kS5Pad = INT32_MIN;    // out[] of a padding entry
+constexpr int kS5MaxWindows = 4096;  // pace windows of a stream (their first steps sit in LDS)
+constexpr int kS5Stride = 16;        // ints between two progress counters (a 64-byte line each)
+
+// Pacing (speed only - no data is handed over, so no fences; every wait is bounded and the kernel computes the same bits with or
+// without it).  The stream of a workgroup is cut into `nw` windows of the catalog (wst[w] = its first step of window w); the
+// workgroups of a launch that share an XCD (blocks b, b + 8, ... under the observed round-robin placement) walk them together:
+// a workgroup may work on window w only when all of them have COMPLETED window w - lag - 1, so the rows being gathered on that XCD
+// at any time span lag + 1 windows, which its L2 holds.  Worker waves note the window they are in in LDS (s_win) and wait on an
+// LDS gate; the 16th wave of the workgroup is the pacer: it publishes the workgroup's completed windows (one relaxed agent-scope
+// add per window to cnt[x][w]) and moves the gate when the counter it waits for reaches the number of peers.  If nothing moves
+// for ~1 ms (a workgroup of the launch is not resident) the pacer opens the gate for good.
+struct S5Pace {
+    const int32_t* wst;   // [n_wg, nw + 1] first step of every window of every workgroup (wst[nw] = steps of the workgroup)
+    int* cnt;             // [8, nw] x kS5Stride progress counters of this launch, zero at launch
+    int nw, lag;
+};
 
 template <int NV, typename T>
-__global__ __launch_bounds__(64 * kS5Waves) void k_wmrb_scores5(const int32_t* __restrict__ ids, const int32_t* __restrict__ outs,
-                                                               const int64_t* __restrict__ wg_ptr, int64_t wg0, int64_t n_users,
-                                                               const T* __restrict__ U, const T* __restrict__ V,
-                                                               float* __restrict__ sp, float* __restrict__ p) {
+__global__ __launch_bounds__(64 * (kS5Waves + 1)) void k_wmrb_scores5(const int32_t* __restrict__ ids, const int32_t* __restrict__ outs,
+                                                                     const int64_t* __restrict__ wg_ptr, int64_t wg0, int64_t n_users,
+                                                                     const T* __restrict__ U, const T* __restrict__ V,
+                                                                     float* __restrict__ sp, float* __restrict__ p, S5Pace pace) {
     constexpr int G = 32, NGB = 2 * kS5Waves;
     constexpr uint32_t RB = RowBytes<G, NV, T>::value;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [kS5Users] rows as stored
-    const int tid = threadIdx.x, lane = tid & 63, g = lane & (G - 1), gid = tid / G;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [kS5Users] rows as stored | [nw + 1] window starts
+    __shared__ int s_win[kS5Waves];
+    __shared__ int s_gate;
+    int* wst = reinterpret_cast<int*>(smem_raw + (size_t)kS5Users * RB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane & (G - 1), gid = tid / G;
     const int64_t wg = wg0 + blockIdx.x;
     const int64_t ubeg = wg * kS5Users;
     const int nu = (int)((n_users - ubeg < kS5Users) ? n_users - ubeg : kS5Users);
+    const bool paced = pace.cnt != nullptr;
     // the workgroup's rows -> LDS, 16 bytes per lane (rows of U are contiguous: one flat copy)
     {
         const tmf_f4* src = reinterpret_cast<const tmf_f4*>(reinterpret_cast<const char*>(U) + ubeg * (int64_t)RB);
         tmf_f4* dst = reinterpret_cast<tmf_f4*>(smem_raw);
-        for (int i = tid; i < nu * (int)(RB / 16); i += 64 * kS5Waves) dst[i] = __builtin_nontemporal_load(src + i);
+        for (int i = tid; i < nu * (int)(RB / 16); i += 64 * (kS5Waves + 1)) dst[i] = __builtin_nontemporal_load(src + i);
+        if (paced)
+            for (int i = tid; i <= pace.nw; i += 64 * (kS5Waves + 1)) wst[i] = pace.wst[wg * (pace.nw + 1) + i];
+        if (tid < kS5Waves) s_win[tid] = 0;
+        if (tid == 0) s_gate = paced ? pace.lag : INT32_MAX;
     }
     __syncthreads();
+    if (wave == kS5Waves) {   // ---- the pacer ----
+        if (!paced) return;
+        const int x = blockIdx.x & 7, peers = ((int)gridDim.x - x + 7) / 8;
+        int* cnt = pace.cnt + (size_t)x * pace.nw * kS5Stride;
+        int published = 0, gate = pace.lag, idle = 0;
+        bool open = false;
+        for (;;) {
+            int mn = (lane < kS5Waves) ? __hip_atomic_load(&s_win[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT32_MAX;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));   // lanes 0..15 hold the workers' windows (lane 15: none)
+            mn = __builtin_amdgcn_readfirstlane(mn);
+            const bool done = mn == INT32_MAX;
+            const int target = done ? pace.nw : mn;       // every wave has left the windows below
+            if (lane == 0)
+                for (int w = published; w < target; ++w) __hip_atomic_fetch_add(cnt + (size_t)w * kS5Stride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (target > published) published = target;
+            if (done) return;
+            if (!open && gate < pace.nw - 1) {
+                int c = (lane == 0) ? __hip_atomic_load(cnt + (size_t)(gate - pace.lag) * kS5Stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= peers) {
+                    ++gate;
+                    idle = 0;
+                    if (lane == 0) __hip_atomic_store(&s_gate, gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    continue;
+                }
+                if (++idle > 4000) {   // ~1 ms without progress: stop pacing rather than wait for a workgroup that is not there
+                    open = true;
+                    if (lane == 0) __hip_atomic_store(&s_gate, INT32_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
     const int64_t beg = wg_ptr[wg], end = wg_ptr[wg + 1];   // multiples of 8 (padded)
-    const int64_t steps = (end - beg) >> 3;
+    const int steps = (int)((end - beg) >> 3);
     const uint32_t loff = 16u * (uint32_t)g;
     const int my_entry = Reduce8x32::entry_of_lane(lane);
     const bool owner = Reduce8x32::owner(lane);
     const int4* id4 = reinterpret_cast<const int4*>(ids + beg);   // 32-byte aligned steps
-    int64_t st = gid;
-    int4 na = make_int4(0, 0, 0, 0), nb = na;
-    int no = kS5Pad;
-    if (st < steps) {
-        na = id4[2 * st];
-        nb = id4[2 * st + 1];
-        no = outs[beg + 8 * st + my_entry];
-    }
-    while (st < steps) {
-        const int4 ia = na, ib = nb;
-        const int o = no;
-        const int64_t nx = st + NGB;
-        if (nx < steps) {   // the next step's ids and places, in flight while this step's rows are gathered
-            na = id4[2 * nx];
-            nb = id4[2 * nx + 1];
-            no = outs[beg + 8 * nx + my_entry];
-        }
-        const int idv[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-        Raw<NV, T> y[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) load_raw32<G, NV>(y[t], V, (uint32_t)idv[t] & 0xffffffu, loff);
-        float pr[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            Raw<NV, T> x;   // the entry's user row, from LDS
-            const char* xr = smem_raw + ((uint32_t)idv[t] >> 24) * RB + loff;
-            if constexpr (std::is_same<T, float>::value) {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) x.v[v] = *reinterpret_cast<const float4*>(xr + 16 * G * v);
-            } else {
-#pragma unroll
-                for (int pv = 0; pv < NV / 2; ++pv) x.v[pv] = *reinterpret_cast<const bf16x8*>(xr + 16 * G * pv);
+    const int32_t* out8 = outs + beg + my_entry;
+    // Step i of this lane group is gid + NGB i; the wave runs as many rounds as its first group has steps (the second has as
+    // many or one fewer: beyond its last step a group repeats it and stores nothing), so every load below is unconditional -
+    // behind a divergent branch the compiler waits for a load at the end of the branch.
+    const int mine = steps > gid ? (steps - gid + NGB - 1) / NGB : 0;
+    const int rounds = __builtin_amdgcn_readfirstlane(mine);
+    if (rounds > 0) {
+        const int last = mine > 0 ? gid + NGB * (mine - 1) : 0;
+        struct Ids {
+            int4 a, b;
+            int o;
+        };
+        auto fetch = [&](int i) {   // ids and place of round i (8 ids: every lane of the group reads the same 32 bytes)
+            const int st = gid + NGB * i;
+            const int sc = st <= last ? st : last;
+            Ids r{id4[2 * sc], id4[2 * sc + 1], out8[8 * sc]};
+            if (i >= mine) r.o = kS5Pad;
+            return r;
+        };
+        int cur_w = 0, next_b = paced ? wst[1] : INT32_MAX;   // the wave's window and the first step of the next one
+        auto pace_to = [&](int i) {   // before the rows of round i are asked for: is the wave allowed into their window?
+            if (!paced) return;
+            const int st_w = __builtin_amdgcn_readfirstlane(gid + NGB * i);   // the wave's first group decides for both
+            if (st_w < next_b) return;
+            do {
+                ++cur_w;
+                next_b = wst[cur_w + 1];
+            } while (st_w >= next_b && cur_w < pace.nw - 1);
+            if (lane == 0) __hip_atomic_store(&s_win[wave], cur_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int spin = 0; spin < 20000; ++spin) {   // bounded: ~2 ms
+                if (__hip_atomic_load(&s_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= cur_w) break;
+                __builtin_amdgcn_s_sleep(2);
             }
-            pr[t] = dot_raw<NV>(x, y[t]);
+        };
+        auto gather = [&](Raw<NV, T> (&y)[8], const Ids& d) {
+            const int idv[8] = {d.a.x, d.a.y, d.a.z, d.a.w, d.b.x, d.b.y, d.b.z, d.b.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) load_raw32<G, NV>(y[t], V, (uint32_t)idv[t] & 0xffffffu, loff);
+        };
+        auto finish = [&](const Raw<NV, T> (&y)[8], const Ids& d) {
+            const int idv[8] = {d.a.x, d.a.y, d.a.z, d.a.w, d.b.x, d.b.y, d.b.z, d.b.w};
+            float pr[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                Raw<NV, T> x;   // the entry's user row, from LDS
+                const char* xr = smem_raw + ((uint32_t)idv[t] >> 24) * RB + loff;
+                if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) x.v[v] = *reinterpret_cast<const float4*>(xr + 16 * G * v);
+                } else {
+#pragma unroll
+                    for (int pv = 0; pv < NV / 2; ++pv) x.v[pv] = *reinterpret_cast<const bf16x8*>(xr + 16 * G * pv);
+                }
+                pr[t] = dot_raw<NV>(x, y[t]);
+            }
+            const float sc = Reduce8x32::run(pr, lane);
+            if (owner && d.o != kS5Pad) __builtin_nontemporal_store(sc, d.o >= 0 ? sp + d.o : p + ~d.o);
+        };
+        // Two rounds in flight per lane group: while the rows of round i are reduced, those of round i + 1 are on their way.
+        // Loads return in order (vmcnt), so a wait is for everything OLDER as well: the ids of round i + 2 are therefore asked for
+        // BEFORE the rows of round i + 1 (waiting for ids then never waits for rows issued after them, and the stream read - it
+        // comes from HBM - has a whole round to arrive before anything behind it is waited for).
+        Raw<NV, T> yA[8], yB[8];
+        Ids A = fetch(0);
+        Ids B = fetch(1);
+        pace_to(0);
+        gather(yA, A);
+        for (int i = 0; i < rounds; i += 2) {
+            Ids C = fetch(i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            pace_to(i + 1);
+            gather(yB, B);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(yA, A);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 >= rounds) break;
+            Ids Dn = fetch(i + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            pace_to(i + 2);
+            gather(yA, C);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(yB, B);
+            __builtin_amdgcn_sched_barrier(0);
+            A = C;
+            B = Dn;
         }
-        const float sc = Reduce8x32::run(pr, lane);
-        if (owner && o != kS5Pad) __builtin_nontemporal_store(sc, o >= 0 ? sp + o : p + ~o);
-        st = nx;
     }
+    if (lane == 0) __hip_atomic_store(&s_win[wave], INT32_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 }  // namespace tmf
 
+static int s5_launches(int64_t n_wg, int wgs_per_launch) { return (int)((n_wg + wgs_per_launch - 1) / wgs_per_launch); }
+static int s5_wgs_per_launch(int wgs_per_launch) {
+    if (wgs_per_launch > 0) return wgs_per_launch;
+    int dev = 0, cus = 256;   // one workgroup per CU: every workgroup of a launch resident, all walking the catalog together
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+
 template <typename T>
 static int wmrb_scores5_impl(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg, int64_t n_users,
                              int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
-                             int wgs_per_launch, void* stream) {
+                             int wgs_per_launch, const int32_t* wstart, int32_t n_windows, int lag, void* workspace,
+                             size_t workspace_bytes, void* stream) {
     if (n_wg == 0 || n_users == 0) return TMF_OK;
     const RowGeom geom = row_geom_of<T>(n_components);
     TMF_REQUIRE(ids && outs && wg_ptr && U && V && sp && p, "wmrb_scores5: null pointer");
@@ -1111,13 +1227,35 @@ static int wmrb_scores5_impl(const int32_t* ids, const int32_t* outs, const int6
                   "in a table below 4 GB (got %d components, %lld items)", n_components, (long long)n_items);
         return TMF_E_UNSUPPORTED;
     }
-    if (wgs_per_launch <= 0) {   // one workgroup per CU: every workgroup of a launch resident, all walking the catalog together
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        wgs_per_launch = cus > 0 ? cus : 256;
+    wgs_per_launch = s5_wgs_per_launch(wgs_per_launch);
+    const int launches = s5_launches(n_wg, wgs_per_launch);
+    const bool paced = wstart != nullptr && workspace != nullptr && n_windows > 1;
+    const size_t per_launch = (size_t)8 * (paced ? n_windows : 0) * kS5Stride * sizeof(int);
+    if (paced) {
+        TMF_REQUIRE(n_windows <= kS5MaxWindows && lag >= 0, "wmrb_scores5: %d windows (at most %d), lag %d", n_windows, kS5MaxWindows, lag);
+        TMF_REQUIRE(workspace_bytes >= per_launch * launches, "wmrb_scores5: workspace of %zu bytes needed, got %zu", per_launch * launches,
+                    workspace_bytes);
+        if (hipMemsetAsync(workspace, 0, per_launch * launches, (hipStream_t)stream) != hipSuccess) {
+            set_error("wmrb_scores5: hipMemsetAsync failed");
+            return TMF_E_LAUNCH;
+        }
     }
-    const size_t lds = row_bytes * kS5Users;
-#define CALL(G_, NV_)                                                                                                           {                                                                                                                               if constexpr (G_ == 32) {                                                                                                       static LdsGrant grant;                                                                                                      if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_wmrb_scores5<NV_, T>), lds, grant)) return rc;              for (int64_t w0 = 0; w0 < n_wg; w0 += wgs_per_launch) {                                                                         const unsigned blocks = (unsigned)((n_wg - w0 < wgs_per_launch) ? n_wg - w0 : wgs_per_launch);                              hipLaunchKernelGGL((k_wmrb_scores5<NV_, T>), dim3(blocks), dim3(64 * kS5Waves), lds, (hipStream_t)stream, ids,                                    outs, wg_ptr, w0, n_users, (const T*)U, (const T*)V, sp, p);                                         }                                                                                                                       }                                                                                                                       }
+    const size_t lds = row_bytes * kS5Users + (paced ? (size_t)(n_windows + 1) * sizeof(int) : 0);
+#define CALL(G_, NV_)                                                                                                       \
+    {                                                                                                                       \
+        if constexpr (G_ == 32) {                                                                                           \
+            static LdsGrant grant;                                                                                          \
+            if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_wmrb_scores5<NV_, T>), lds, grant)) return rc;  \
+            for (int l = 0; l < launches; ++l) {                                                                            \
+                const int64_t w0 = (int64_t)l * wgs_per_launch;                                                             \
+                const unsigned blocks = (unsigned)((n_wg - w0 < wgs_per_launch) ? n_wg - w0 : wgs_per_launch);              \
+                const S5Pace pace{wstart, paced ? reinterpret_cast<int*>(static_cast<char*>(workspace) + per_launch * l) : nullptr, \
+                                  n_windows, lag};                                                                          \
+                hipLaunchKernelGGL((k_wmrb_scores5<NV_, T>), dim3(blocks), dim3(64 * (kS5Waves + 1)), lds, (hipStream_t)stream, \
+                                   ids, outs, wg_ptr, w0, n_users, (const T*)U, (const T*)V, sp, p, pace);                  \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
     TMF_DISPATCH(T, geom, CALL);
 #undef CALL
     return check_launch("tmf_wmrb_scores5");
@@ -1149,9 +1287,11 @@ static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users
     }                                                                                                                     \
     extern "C" int tmf_wmrb_scores5_##SFX(const int32_t* ids, const int32_t* outs, const int64_t* wg_ptr, int64_t n_wg,    \
                                           int64_t n_users, int64_t n_items, const void* U, const void* V, float* sp,      \
-                                          float* p, int n_components, int wgs_per_launch, void* stream) {                 \
+                                          float* p, int n_components, int wgs_per_launch, const int32_t* wstart,          \
+                                          int32_t n_windows, int lag, void* workspace, size_t workspace_bytes,            \
+                                          void* stream) {                                                                 \
         return wmrb_scores5_impl<T_>(ids, outs, wg_ptr, n_wg, n_users, n_items, U, V, sp, p, n_components, wgs_per_launch, \
-                                     stream);                                                                             \
+                                     wstart, n_windows, lag, workspace, workspace_bytes, stream);                         \
     }                                                                                                                     \
     extern "C" int tmf_wmrb_gradu3_##SFX(const tmf_slice_lists* lists, const float* D, const float* delta,                \
                                          const void* V, float* part, int per_slice_launches, int n_components,            \
@@ -1173,6 +1313,10 @@ TMF_SLICED_ENTRY_POINTS(f32, float)
 TMF_SLICED_ENTRY_POINTS(bf16, __bf16)
 
 extern "C" int tmf_wmrb_scores5_users_per_workgroup(void) { return tmf::kS5Users; }
+extern "C" size_t tmf_wmrb_scores5_workspace_bytes(int64_t n_wg, int32_t n_windows, int wgs_per_launch) {
+    if (n_wg <= 0 || n_windows <= 1) return 0;
+    return (size_t)s5_launches(n_wg, s5_wgs_per_launch(wgs_per_launch)) * 8 * (size_t)n_windows * tmf::kS5Stride * sizeof(int);
+}
 extern "C" int tmf_wmrb_scores5_supported(int n_components, int bf16, int64_t n_items) {
     const tmf::RowGeom geom = bf16 ? tmf::row_geom_bf16(n_components) : tmf::row_geom(n_components);
     const int64_t row_bytes = (int64_t)geom.ld * (bf16 ? 2 : 4);

@@ -111,16 +111,42 @@ def test_scores5_one_step_against_the_fp64_closed_form(eng, monkeypatch):
     assert_step(b['V'][:, :r].cpu().numpy(), V64, t['gV'], lr, what='scores5 V', slack=sl['gV'])
 
 
-def test_scores5_is_chosen_for_short_visits_only(eng, monkeypatch):
-    """The default: scores5 where an L2-sized slice would leave a (user, slice) visit fewer than 24 rows (huge catalogs), scores3
-    otherwise; unsupported geometries never."""
-    monkeypatch.delenv('TMF_SCORES5', raising=False)
-
+def test_scores5_is_opt_in_only(eng, monkeypatch):
+    """Measured slower than scores3 on the shape it was built for (profiles/r04_scores5_experiment.txt): never chosen unless
+    TMF_SCORES5=1, and then only for the geometries the kernel has."""
     class P:
         pass
-    for n_items, r, dtype, S, want in ((1_000_000, 256, torch.bfloat16, 1024, True), (100_000, 128, torch.float32, 1024, False),
-                                       (1_000_000, 64, torch.float32, 1024, False), (20_000_000, 128, torch.float32, 1024, False)):
+    for n_items, r, dtype, has_kernel in ((1_000_000, 256, torch.bfloat16, True), (100_000, 128, torch.float32, True),
+                                          (1_000_000, 64, torch.float32, False), (20_000_000, 128, torch.float32, False)):
         plan, w = P(), P()
         plan.n_items, plan.nnz, plan.n_users, plan.col_u = n_items, 100 * 1000, 1000, torch.zeros(1, device='cuda')
-        w.sliced, w.S = True, S
-        assert eng.scores5_wanted(plan, w, r, dtype) == want, (n_items, r)
+        w.sliced, w.S = True, 1024
+        monkeypatch.delenv('TMF_SCORES5', raising=False)
+        assert not eng.scores5_wanted(plan, w, r, dtype)
+        monkeypatch.setenv('TMF_SCORES5', '1')
+        assert eng.scores5_wanted(plan, w, r, dtype) == has_kernel, (n_items, r)
+
+
+@pytest.mark.parametrize('lag', [0, 2])
+def test_scores5_pacing_changes_nothing(eng, monkeypatch, lag):
+    """The pacer (16th wave, per-XCD progress counters, LDS gate) is speed only: tiny windows and lag 0 make the workgroups
+    really wait for each other (20 workgroups, up to 3 per XCD lane) - the scores must be those of the free-running kernel,
+    bit for bit, and so must a second paced run."""
+    m, n, r, S = 5000, 20000, 128, 64
+    idx, val, R, U, V = problem(m, n, r, S, 60000, seed=11)
+    monkeypatch.setenv('TMF_S5_PACE', '0')
+    free = epoch(eng, monkeypatch, True, idx, val, R, U, V, m, n, r, S, torch.float32, 3)
+    assert not free['wplan'].s5.paced
+    monkeypatch.setenv('TMF_S5_PACE', '1')
+    monkeypatch.setenv('TMF_S5_SLICE_BYTES', str(64 * 512))    # slices of 64 rows: 313 of them
+    monkeypatch.setenv('TMF_S5_PACE_EVERY', '2')               # a rendezvous every second slice
+    monkeypatch.setenv('TMF_S5_LAG', str(lag))
+    a = epoch(eng, monkeypatch, True, idx, val, R, U, V, m, n, r, S, torch.float32, 3)
+    b = epoch(eng, monkeypatch, True, idx, val, R, U, V, m, n, r, S, torch.float32, 3)
+    s5 = a['wplan'].s5
+    assert s5.paced and s5.n_slices > 300 and s5.n_windows == (s5.n_slices + 1) // 2 + 1 and s5.lag == lag
+    ws = s5.wstart.cpu().numpy()
+    assert (np.diff(ws, axis=1) >= 0).all() and (ws[:, :2] == 0).all()      # window 0 is the (empty) start line
+    assert np.array_equal(ws[:, -1], np.diff(s5.wg_ptr.cpu().numpy()) // 8)
+    for k in ('sp', 'pk', 'U', 'V'):
+        assert torch.equal(a[k], free[k]) and torch.equal(a[k], b[k]), k
