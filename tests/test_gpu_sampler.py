@@ -74,3 +74,29 @@ def test_constructor_draws_on_the_device_above_the_host_limit():
     np.random.seed(7)
     want = np.array([np.random.choice(a=40, size=10, replace=False) for _ in range(30)])
     assert np.array_equal(small.random_ind.cpu().numpy(), want)
+
+
+def test_bench_generator_blocks_equal_the_whole_problem_on_the_device():
+    """bench.py's synthetic problem is per-user seeded (tests/test_bench_cpu.py on the CPU): on the device, with the transcendental
+    functions of the GPU, the blocks four ranks would generate are the whole problem bit for bit - interactions, values, negatives."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from teamoflow_amd import _engine
+    from teamoflow_amd import dist as tdist
+    from teamoflow_amd.mf.utils import random_sampler_device
+    dev = torch.device('cuda', 0)
+    m, n, target, S = 40_000, 5_000, 2_000_000, 64
+    plan = bench.calibrated_degrees(m, n, target, 'zipf', 0, dev)
+    idx, val = bench.gen_interactions(m, n, target, 'zipf', 0, dev, plan=plan)
+    assert abs(len(val) - target) < 0.02 * target
+    bounds = tdist.partition_users(_engine._excl_cumsum(plan[0]), 4, per_user_cost=S)
+    parts = [bench.gen_interactions(m, n, target, 'zipf', 0, dev, users=(b, e), plan=plan) for b, e in zip(bounds[:-1], bounds[1:])]
+    assert torch.equal(torch.cat([p[0] for p in parts]), idx) and torch.equal(torch.cat([p[1] for p in parts]), val)
+    R = random_sampler_device(n, m, S, seed=100, device=dev)
+    Rp = [random_sampler_device(n, e - b, S, seed=100, device=dev, user_offset=b) for b, e in zip(bounds[:-1], bounds[1:])]
+    assert torch.equal(torch.cat(Rp), R)
+    # the CPU draws the same table (integer arithmetic only)
+    assert torch.equal(random_sampler_device(n, 300, S, seed=100, device='cpu', user_offset=777), R[777:1077].cpu())
