@@ -371,6 +371,12 @@ extern "C" int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, floa
 //                         buffer, no overflow path, and k = 64 costs per insertion what k = 13 costs; thresholds are refreshed
 //                         in registers after every insertion.  One copy of the code walks the rows by a wave-uniform
 //                         register index (sixteen unrolled copies overflowed the instruction cache).
+//   FCAND_MERGE (round 4, large k)  append like FCAND_PEND (32 pending entries per row); a row whose buffer is half full is merged by
+//                         the WHOLE wave: the pending entries are bitonic-sorted worst-first in the upper half-wave (15
+//                         compare-exchange stages), one element-wise "keep the better" against the best-first list leaves the 64
+//                         best of both as a bitonic sequence, six more stages sort it - 22 stages for up to 32 candidates instead
+//                         of one ~160-instruction insertion for each.  The comparator is the total order (value desc, index asc),
+//                         so the merged list is THE sorted list whatever the network does with ties.
 // Items arrive in ascending index order, so "strictly greater than the k-th value" at the start of a tile is exactly
 // tf.math.top_k's tie rule; inside a tile the full comparator decides.  Measured (r = 128, 262144 x 100000, same box,
 // TF pending / insertion): k = 10: 118.5 / 115.3, 16: 89.9 / 110.0, 24: 77.1 / 103.6, 32: 65.9 / 75.7, 64: 36.4 / 61.1.
@@ -380,7 +386,13 @@ extern "C" int tmf_gather_rows_cols_f32(const float* X, const int64_t* idx, floa
 namespace tmf {
 
 constexpr int FBM = 128, FBN = 128, FBK = 32, FLD = FBN + 1, FCAP = 16, FMAXK = 64;
-constexpr int FCAND_PEND = 0, FCAND_INS = 1;   // candidate handling of k_predict_topk: pending buffers + rare merges, or immediate insertion
+constexpr int FCAND_PEND = 0, FCAND_INS = 1, FCAND_MERGE = 2;   // candidate handling of k_predict_topk: pending buffers + rare one-lane merges,
+                                                                // immediate 64-lane insertion, or pending buffers + wave-wide bitonic merges
+constexpr int FPC = 32;   // FCAND_MERGE: pending entries per row
+#ifndef TMF_FPT
+#define TMF_FPT 24
+#endif
+constexpr int FPT = TMF_FPT;   // ... and the fill from which a row is merged after a tile (a 16-column group of the overflow path: FPC / 2)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 2: K % 4 == 0 and V < 4 GB (buffer loads, constant per-thread offsets), 1: K % 4 == 0 (branch-free), 0: any K
@@ -397,13 +409,58 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
     return (unsigned)r[0] | (unsigned)r[1];
 }
 
+// x of lane (lane ^ STRIDE), without the LDS crossbar: DPP quad permutes (1, 2), two bank-masked row shifts (4), row_ror:8 (8),
+// the gfx950 half-row / half-wave swaps + a select (16, 32)
+template <int STRIDE>
+__device__ __forceinline__ unsigned lane_xor(unsigned x, int lane) {
+    const int v = (int)x;
+    if constexpr (STRIDE == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    else if constexpr (STRIDE == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    else if constexpr (STRIDE == 4) {
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);    // row_shl:4 into the lanes with bit 2 clear
+        return (unsigned)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xA, false);   // row_shr:4 into the others
+    } else if constexpr (STRIDE == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    else if constexpr (STRIDE == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // r[0] = even rows twice, r[1] = odd rows twice
+        return (unsigned)((lane & 16) ? r[0] : r[1]);
+    } else {
+        static_assert(STRIDE == 32, "lane distances 1 .. 32");
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0] = lower half twice, r[1] = upper half twice
+        return (unsigned)((lane & 32) ? r[0] : r[1]);
+    }
+}
+
+// (value, index) as ONE orderable 64-bit key: a ranks before b under (value desc, index asc)  <=>  key(a) > key(b).
+// (NaN scores never become candidates; -0 and +0 map to different keys, like the comparator's v == v test they are told apart
+// nowhere else: both are only ever produced by the clamp, as +0.)
+__device__ __forceinline__ unsigned long long rank_key(float v, int ix) {
+    const unsigned u = __float_as_uint(v);
+    const unsigned o = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned)(0x7fffffff - ix);
+}
+__device__ __forceinline__ void rank_unkey(unsigned long long key, float& v, int& ix) {
+    const unsigned o = (unsigned)(key >> 32);
+    v = __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
+    ix = 0x7fffffff - (int)(unsigned)key;
+}
+
+// One compare-exchange stage of a sorting network over lane distance STRIDE on 64-bit keys: the lane with the STRIDE bit clear
+// keeps the larger key when `big_first`, else the smaller.
+template <int STRIDE>
+__device__ __forceinline__ void key_cmpx(unsigned long long& key, bool big_first, int lane) {
+    const unsigned olo = lane_xor<STRIDE>((unsigned)key, lane), ohi = lane_xor<STRIDE>((unsigned)(key >> 32), lane);
+    const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+    const bool keep_big = ((lane & STRIDE) == 0) == big_first;
+    key = (keep_big == (other > key)) ? other : key;
+}
+
 template <int NCH, int MODE, int CAND>  // K_PAD = 32 * NCH; CAND: how candidates reach the rows' sorted lists (FCAND_*)
 __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const float* __restrict__ A, const float* __restrict__ B,
                                                          int64_t m, int64_t n, int K, int64_t lda, int64_t ldb, int k,
                                                          int clamp, int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_val) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr bool PEND = CAND == FCAND_PEND;
+    constexpr bool PEND = CAND == FCAND_PEND, MERGE = CAND == FCAND_MERGE;
     float* Bs = reinterpret_cast<float*>(smem_raw);          // [3][FBK][FLD]
     // FCAND_PEND (k <= 12): thresholds, per-row pending buffers and [k][FBM] sorted lists, merged by one lane per row
     float* tau = Bs + 3 * FBK * FLD;                         // [FBM]
@@ -415,6 +472,11 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
     int* plist_i = reinterpret_cast<int*>(plist_v + (size_t)k * FBM);
     float* list_v = Bs + 3 * FBK * FLD;                      // FCAND_INS: [FBM][k], every row's k best so far, sorted (value desc, index asc)
     int* list_i = reinterpret_cast<int*>(list_v + (size_t)FBM * k);
+    // FCAND_MERGE: tau / cnt / ovf as FCAND_PEND, then row-major pending buffers [FBM][FPC] and row-major lists [FBM][k]
+    float* mpend_v = reinterpret_cast<float*>(ovf + 4);
+    int* mpend_i = reinterpret_cast<int*>(mpend_v + FPC * FBM);
+    float* mlist_v = reinterpret_cast<float*>(mpend_i + FPC * FBM);
+    int* mlist_i = reinterpret_cast<int*>(mlist_v + (size_t)FBM * k);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int64_t row0 = (int64_t)blockIdx.x * FBM;
@@ -442,6 +504,12 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
             for (int j = 0; j < k; ++j) { plist_v[j * FBM + t] = -INFINITY; plist_i[j * FBM + t] = 0x7fffffff; }
         }
         if (tid == 0) ovf[0] = 0;
+    } else if constexpr (MERGE) {
+        for (int t = tid; t < FBM; t += 256) {
+            tau[t] = (row0 + t < m) ? -INFINITY : INFINITY;
+            cnt[t] = 0;
+        }
+        for (int t = tid; t < FBM * k; t += 256) { mlist_v[t] = -INFINITY; mlist_i[t] = 0x7fffffff; }
     } else {
         for (int t = tid; t < FBM * k; t += 256) { list_v[t] = -INFINITY; list_i[t] = 0x7fffffff; }
     }
@@ -612,7 +680,7 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
 #pragma unroll
         for (int q = 0; q < 16; ++q) tq[q] = tau[32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h];
     };
-    if constexpr (PEND) load_tau();
+    if constexpr (PEND || MERGE) load_tau();
     auto offer = [&](int64_t col0, int group, unsigned pass) {
         // group < 0: every column; otherwise only local columns [16 group, 16 group + 16)
         // (a ballot + popcount slot assignment instead of the LDS atomic was measured slower: it makes all 64 lanes walk
@@ -658,8 +726,85 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
         }
     };
 
+    // ---- FCAND_MERGE: append like FCAND_PEND (row-major buffers), merge a row with the whole wave ----
+    auto offer_m = [&](int64_t col0, int group, unsigned pass) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (!((pass >> q) & 1u)) continue;
+            const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float t = tau[row];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lc = 32 * j + l31;
+                float v = acc[j][q];
+                if (clamp) v = (v > 0.f) ? v : 0.f;
+                const bool in_group = (group < 0) || ((lc >> 4) == group);
+                if (in_group && (col0 + lc < n) && v > t) {
+                    const int pos = atomicAdd(&cnt[row], 1);
+                    if (pos < FPC) { mpend_v[row * FPC + pos] = v; mpend_i[row * FPC + pos] = (int)(col0 + lc); }
+                }
+            }
+        }
+    };
+    auto merge_row = [&](int row) {   // wave-uniform row; all 64 lanes
+        const int c = cnt[row] < FPC ? cnt[row] : FPC;
+        const unsigned long long worst = rank_key(-INFINITY, 0x7fffffff);
+        // the list, best first (largest key first); lanes past k: worst
+        unsigned long long a = lane < k ? rank_key(mlist_v[row * k + lane], mlist_i[row * k + lane]) : worst;
+        // the pending entries in the TOP lanes of the wave - 8, 16 or 32 of them, whichever holds them all - bitonic-sorted worst
+        // (smallest key) first; the lanes below hold equal "worst" keys: already in place
+        const int W = c <= 8 ? 8 : (c <= 16 ? 16 : 32);   // wave-uniform
+        const int pl = lane - (64 - W);
+        unsigned long long pk = (pl >= 0 && pl < c) ? rank_key(mpend_v[row * FPC + pl], mpend_i[row * FPC + pl]) : worst;
+        key_cmpx<1>(pk, (lane & 2) != 0, lane);
+        key_cmpx<2>(pk, (lane & 4) != 0, lane);
+        key_cmpx<1>(pk, (lane & 4) != 0, lane);
+        key_cmpx<4>(pk, W > 8 && (lane & 8) != 0, lane);
+        key_cmpx<2>(pk, W > 8 && (lane & 8) != 0, lane);
+        key_cmpx<1>(pk, W > 8 && (lane & 8) != 0, lane);
+        if (W > 8) {
+            key_cmpx<8>(pk, W > 16 && (lane & 16) != 0, lane);
+            key_cmpx<4>(pk, W > 16 && (lane & 16) != 0, lane);
+            key_cmpx<2>(pk, W > 16 && (lane & 16) != 0, lane);
+            key_cmpx<1>(pk, W > 16 && (lane & 16) != 0, lane);
+        }
+        if (W > 16) {
+            key_cmpx<16>(pk, false, lane);
+            key_cmpx<8>(pk, false, lane);
+            key_cmpx<4>(pk, false, lane);
+            key_cmpx<2>(pk, false, lane);
+            key_cmpx<1>(pk, false, lane);
+        }
+        // list best-first against pending worst-first: the better of each pair = the 64 best of both, as a bitonic sequence
+        a = pk > a ? pk : a;
+        key_cmpx<32>(a, true, lane);
+        key_cmpx<16>(a, true, lane);
+        key_cmpx<8>(a, true, lane);
+        key_cmpx<4>(a, true, lane);
+        key_cmpx<2>(a, true, lane);
+        key_cmpx<1>(a, true, lane);
+        float av;
+        int ai;
+        rank_unkey(a, av, ai);
+        if (lane < k) { mlist_v[row * k + lane] = av; mlist_i[row * k + lane] = ai; }
+        const float kth = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), k - 1));
+        if (lane == 0) {
+            cnt[row] = 0;
+            tau[row] = kth;   // rows past m never get here (their threshold is +inf: nothing is ever appended)
+        }
+    };
+    auto merge_rows = [&](unsigned rows) {   // wave-uniform mask over the wave's 32 rows
+        wave_lds_sync();
+        while (rows) {
+            const int l = __builtin_ctz(rows);
+            rows &= rows - 1;
+            merge_row(32 * wave + l);
+        }
+        wave_lds_sync();
+    };
+
     int64_t g = 0;
-    int c_prev = 0;  // FCAND_PEND, lanes h == 0: pending entries of the lane's row that predate the current tile
+    int c_prev = 0;  // FCAND_PEND / FCAND_MERGE, lanes h == 0: pending entries of the lane's row that predate the current tile
     for (int64_t tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -728,12 +873,45 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
                 }
             }
 
+        } else if constexpr (MERGE) {
+            const int64_t col0 = tile * FBN;
+            const unsigned pass = prefilter();
+            if (__any(pass != 0u)) {  // wave-uniform
+                offer_m(col0, -1, pass);
+                wave_lds_sync();
+                const int my_row = 32 * wave + l31;
+                const int c_now = (h == 0) ? cnt[my_row] : 0;
+                if (__any(c_now > FPC)) {
+                    // overflow: drop this tile's partial appends (keep the older ones), merge, then re-offer the tile in 8 groups
+                    // of 16 columns with a merge after each (thresholds only rise: `pass` stays a superset)
+                    // Only rows whose buffer is half full are merged: a group adds at most 16 entries to a row, so a row below
+                    // FPC / 2 cannot overflow in the next group (merging every row with anything pending after every group cost
+                    // 256 merges per tile in the first tiles of a scan).
+                    if (h == 0) cnt[my_row] = c_prev;
+                    merge_rows((unsigned)__builtin_amdgcn_ballot_w64(h == 0 && c_prev >= FPC / 2));
+                    for (int grp = 0; grp < FBN / 16; ++grp) {
+                        offer_m(col0, grp, pass);
+                        wave_lds_sync();
+                        merge_rows((unsigned)__builtin_amdgcn_ballot_w64(h == 0 && cnt[my_row] >= FPC / 2));
+                    }
+                    c_prev = (h == 0) ? cnt[my_row] : 0;
+                    load_tau();
+                } else {
+                    const unsigned due = (unsigned)__builtin_amdgcn_ballot_w64(h == 0 && c_now >= FPT);
+                    if (due) {
+                        merge_rows(due);
+                        load_tau();
+                    }
+                    c_prev = (h == 0) ? cnt[my_row] : 0;
+                }
+            }
         } else {
             const unsigned pass = prefilter();
             if (__builtin_amdgcn_ballot_w64(pass != 0u) != 0) take_candidates(tile * FBN, pass);   // wave-uniform
         }
     }
     if constexpr (PEND) merge_wave();  // whatever is still pending
+    if constexpr (MERGE) merge_rows((unsigned)__builtin_amdgcn_ballot_w64(h == 0 && cnt[32 * wave + l31] > 0));
     __syncthreads();
     if constexpr (PEND) {
         if (tid < FBM && row0 + tid < m) {
@@ -744,10 +922,12 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void k_predict_topk(const fl
         }
     } else {
         // the lists are [row][k] like the output: one coalesced copy
+        const float* Lv = MERGE ? mlist_v : list_v;
+        const int* Li = MERGE ? mlist_i : list_i;
         const int64_t live = (m - row0 < FBM) ? m - row0 : FBM;
         for (int64_t t = tid; t < live * k; t += 256) {
-            out_idx[row0 * k + t] = list_i[t];
-            if (out_val) out_val[row0 * k + t] = list_v[t];
+            out_idx[row0 * k + t] = Li[t];
+            if (out_val) out_val[row0 * k + t] = Lv[t];
         }
     }
 }
@@ -756,6 +936,7 @@ template <int NCH, int MODE, int CAND>
 static int launch_predict_topk_mode(const float* A, const float* B, int64_t m, int64_t n, int K, int64_t lda, int64_t ldb,
                                int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
     const size_t lds = CAND == FCAND_PEND ? sizeof(float) * (3 * FBK * FLD + FBM) + sizeof(int) * (FBM + 4) + 8 * (size_t)FCAP * FBM + 8 * (size_t)k * FBM
+                       : CAND == FCAND_MERGE ? sizeof(float) * (3 * FBK * FLD + FBM) + sizeof(int) * (FBM + 4) + 8 * (size_t)FPC * FBM + 8 * (size_t)k * FBM
                        : sizeof(float) * (3 * FBK * FLD) + 8 * (size_t)k * FBM;
     static LdsGrant grant;  // per template instance
     if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk<NCH, MODE, CAND>), lds, grant)) return rc;
@@ -770,9 +951,12 @@ static int launch_predict_topk_impl(const float* A, const float* B, int64_t m, i
                                int k, int clamp, int32_t* out_idx, float* out_val, hipStream_t stream) {
     // same box, r = 128, TF by k (pending + merge / insertion): 10: 118.5 / 115.3   16: 89.9 / 110.0   24: 77.1 / 103.6
     // 32: 65.9 / 75.7   48: 48.3 / 67.3   64: 36.4 / 61.1 (profiles/r03_predict_candidates.txt)
-    int cand = k <= 12 ? FCAND_PEND : FCAND_INS;
-    if (const char* env = getenv("TMF_PREDICT_CAND")) cand = atoi(env) ? FCAND_INS : FCAND_PEND;   // A/B runs
+    // round 4, same box, r = 128, TF (insertion / wave-wide merges): 16: 109.4 / 94.8   24: 103.4 / 91.4   32: 76.2 / 88.6   48: 67.4 / 83.8
+    // 64: 61.1 / 80.1 - the insertion path keeps two workgroups per CU up to k = 27, beyond that the merges win
+    int cand = k <= 12 ? FCAND_PEND : (k <= 27 ? FCAND_INS : FCAND_MERGE);
+    if (const char* env = getenv("TMF_PREDICT_CAND")) cand = atoi(env);   // A/B runs: 0 pending, 1 insertion, 2 wave-wide merges
     if (cand == FCAND_PEND) return launch_predict_topk_mode<NCH, MODE, FCAND_PEND>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
+    if (cand == FCAND_MERGE) return launch_predict_topk_mode<NCH, MODE, FCAND_MERGE>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
     return launch_predict_topk_mode<NCH, MODE, FCAND_INS>(A, B, m, n, K, lda, ldb, k, clamp, out_idx, out_val, stream);
 }
 

@@ -127,3 +127,28 @@ def test_tiny_tables_keep_their_values_in_the_two_plane_form(ops):
     ref = U.double() @ V.double().T
     want = torch.gather(ref, 1, idx.cpu().long())
     assert float(vals.abs().min()) > 0 and float(((vals.cpu().double() - want).abs() / ref.abs().amax(1, keepdim=True)).max()) < 1e-5
+
+
+@pytest.mark.parametrize('cand', ['0', '1', '2'])
+@pytest.mark.parametrize('k', [1, 10, 28, 33, 64])
+def test_every_candidate_path_keeps_the_tie_rule(ops, monkeypatch, cand, k):
+    """tf.math.top_k: value descending, equal values lower index first (matrix_factorization.py:245, 429-438).  The three ways
+    candidates reach a row's list in the fp32 fused kernel - pending buffer + one-lane merges, 64-lane insertion, pending
+    buffer + wave-wide bitonic merges (round 4, the default from k = 28) - on a catalog where ties are everywhere: a few
+    distinct score levels, thousands of items on each, and a clamp that ties every negative score at 0."""
+    from oracle import sparse_ref as S
+    monkeypatch.setenv('TMF_PREDICT_CAND', cand)
+    g = torch.Generator().manual_seed(k)
+    m, n, r = 300, 9001, 16
+    U = torch.zeros(m, r)
+    V = torch.zeros(n, r)
+    U[:, 0] = torch.randint(1, 4, (m,), generator=g).float()
+    V[:, 0] = torch.randint(-2, 3, (n,), generator=g).float()            # five score levels per user, ~1800 items on each
+    U[:, 1] = 1.0
+    V[::1000, 1] = 0.5                                                    # and a few items lifted off their level
+    sc = (U @ V.T).numpy()
+    for clamp in (False, True):
+        vals, idx = ops.predict_topk(U, V, k, clamp_negatives=clamp, return_values=True, arithmetic='fp32')
+        ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
+        assert np.array_equal(idx.cpu().numpy(), ref), (cand, k, clamp)
+        assert np.array_equal(vals.cpu().numpy(), np.take_along_axis(np.where(sc > 0, sc, 0) if clamp else sc, ref, 1))
