@@ -59,14 +59,17 @@ __device__ __forceinline__ void search_step(const float* __restrict__ ts, const 
     for (int j = 0; j < HSPL; ++j) pp[j] += (tv[j] <= x[j]) ? SP : 0;
 }
 
-__device__ __forceinline__ void search_tile(const float* __restrict__ ts, const float (&x)[HSPL], int (&rho)[HSPL]) {
+// `nfin` = finite thresholds of the chunk (they sort to the front; everything behind them is +inf).  A step whose probe position
+// lies at or beyond nfin reads +inf and never moves: the search starts at the first step that can (a chunk of <= 63 thresholds - most
+// users - takes 6 steps instead of 8, <= 31 five).  Wave-uniform choice; the result is the same by construction.
+__device__ __forceinline__ void search_tile(const float* __restrict__ ts, const float (&x)[HSPL], int (&rho)[HSPL], int nfin) {
     int pp[HSPL];
 #pragma unroll
     for (int j = 0; j < HSPL; ++j) pp[j] = 0;
-    search_step<128>(ts, x, pp);
-    search_step<64>(ts, x, pp);
-    search_step<32>(ts, x, pp);
-    search_step<16>(ts, x, pp);
+    if (nfin >= 128) search_step<128>(ts, x, pp);
+    if (nfin >= 64) search_step<64>(ts, x, pp);
+    if (nfin >= 32) search_step<32>(ts, x, pp);
+    if (nfin >= 16) search_step<16>(ts, x, pp);
     search_step<8>(ts, x, pp);
     search_step<4>(ts, x, pp);
     search_step<2>(ts, x, pp);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
                 float x[HSPL];
                 int rho[HSPL];
                 load_tile(spu, tile * 64 * HSPL, S, lane, x);
-                search_tile(L.ts, x, rho);
+                search_tile(L.ts, x, rho, nfin);
 #pragma unroll
                 for (int j = 0; j < HSPL; ++j) {
                     if (rho[j] == nfin) {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
                 } else {  // only the ranks of the first two tiles stay in registers: search again
                     float x[HSPL];
                     load_tile(spu, tile * 64 * HSPL, S, lane, x);
-                    search_tile(L.ts, x, rho);
+                    search_tile(L.ts, x, rho, nfin);
                 }
 #pragma unroll
                 for (int j = 0; j < HSPL; ++j) {
