@@ -16,3 +16,4 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 # L2 hit rate (TCC_HIT / (TCC_HIT + TCC_MISS)), its own pass
 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_tcc -- python3 $R/bench.py --no-extras --steps 2 --warmup 1 "$@" > /dev/null 2> $OUT/pmc_tcc.err
 python3 $R/tools/profile_summary.py $OUT $TAG
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_tcc   # raw per-dispatch CSVs (tens of MB): gpurun copies back at most 64 MiB; summary/ stays
