@@ -226,7 +226,10 @@ def roofline_report(models, prof, pmc=None):
                      note=f"measured fabric rate {rate / 1e12:.2f} TB/s (L2-miss + write traffic, L2 hit rate {meas.get('l2_hit_rate')}) is above the "
                           f"{HBM_COPY_MEASURED / 1e12:.2f} TB/s the guide measures for a float4 copy from HBM: FETCH_SIZE counts Infinity-Cache "
                           f"hits too, so these are NOT all HBM bytes; priced against the guide's {FABRIC_GATHER_MEASURED / 1e12:.1f} TB/s "
-                          f"Infinity-Cache row-gather rate; traffic is {meas['bytes'] / k['hbm']:.1f}x the compulsory bytes" + extra)
+                          f"Infinity-Cache row-gather rate; traffic is {meas['bytes'] / k['hbm']:.1f}x the compulsory bytes" + extra
+                          + ('; ABOVE that rate: the x2 correction of FETCH_SIZE (16-byte-per-lane reads) also doubles whatever the kernel '
+                             'reads 4 bytes per lane (the item pass: its gathered weights), so the true figure is lower'
+                             if rate > FABRIC_GATHER_MEASURED else ''))
         if k['roof'] == 'l2' and rate is not None and rate / HBM_PEAK >= FABRIC_BOUND_FROM and rate / HBM_PEAK > e['l2_frac']:
             # blocked for the L2s, but the counters say the memory-side fabric is the roof that binds (config-5 shard: L2 hit rate
             # 0.41, 7 - 9 TB/s of fabric traffic - at or above the measured copy ceiling): price the kernel where it is bound.
