@@ -545,6 +545,16 @@ class Workload:
             # rank computes the O(m) degree vector and generates ONLY its own block (gen_interactions is per-user seeded)
             gplan = calibrated_degrees(m, n, nnz_target, args.item_dist, 0, dev)
             bounds = tdist.partition_users(_engine._excl_cumsum(gplan[0]), world, per_user_cost=S if loss == 'wmrb' else 0)
+            if torch.distributed.is_initialized():
+                # every rank derived the partition by itself: they must agree (they do when the ranks compute alike - same device
+                # type, same library; a disagreement would silently drop or duplicate users)
+                red = 'cpu' if torch.distributed.get_backend() == 'gloo' else dev
+                lo = torch.tensor(bounds, dtype=torch.int64, device=red)
+                hi = lo.clone()
+                torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+                torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+                if not torch.equal(lo, hi):
+                    raise RuntimeError(f'ranks disagree on the user partition: {lo.tolist()} .. {hi.tolist()}')
             b, e = bounds[rank], bounds[rank + 1]
             idx, val = gen_interactions(m, n, nnz_target, args.item_dist, 0, dev, users=(b, e), plan=gplan)
             idx[:, 0] -= b
