@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TMF_VERSION 202 /* 0.2.2: tmf_slice_lists is 72 bytes (xcd_major), predict split / half2 / rows4 / gradu4 entry points */
+#define TMF_VERSION 202 /* 0.2.2: tmf_slice_lists is 80 bytes (xcd_major, n_items), predict split / half2 / rows4 / gradu4 entry points */
 
 #define TMF_OK 0
 #define TMF_E_INVALID (-1)   /* bad argument (null pointer, unsupported rank, size mismatch) */
@@ -188,6 +188,9 @@ typedef struct tmf_slice_lists {
      * XCD L2 holds a copy of it), 1 = XCD-major (the XCD of block b - b mod 8 under the observed round-robin placement -
      * walks the slices slice_begin + 8 i + (b mod 8): eight different slices resident, one per L2). */
     int32_t xcd_major;
+    /* Items in the catalog the ids of R_sorted / col index (the rows of V), or 0 = not stated.  Speed only: when stated and
+     * n_items * row bytes < 2^32, tmf_wmrb_scores3 addresses V with 32-bit offsets (one instruction per row address). */
+    int32_t n_items;
 } tmf_slice_lists;
 /* Kernels, called in this order on one stream (tables float (_f32) or bf16 (_bf16) rows as void*; sp / p / D / delta /
  * part / w_ent are fp32):

@@ -428,7 +428,7 @@ class WmrbPlan:
             m, S = self.R.shape
             self._lists = _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(),
                                           plan.col_u.data_ptr(), self.pos_off.data_ptr(), m, S, self.n_slices, 0, 0, 0,
-                                          int(self.xcd_major))
+                                          int(self.xcd_major), int(plan.n_items))
         return ctypes.byref(self._lists)
 
     def window_lists(self, plan, slice_begin, slice_count, item_base):
@@ -436,7 +436,8 @@ class WmrbPlan:
         from item_base on (item-row-sharded V).  The caller keeps the returned struct alive."""
         m, S = self.R.shape
         return _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(), plan.col_u.data_ptr(),
-                               self.pos_off.data_ptr(), m, S, self.n_slices, slice_begin, slice_count, item_base)
+                               self.pos_off.data_ptr(), m, S, self.n_slices, slice_begin, slice_count, item_base, 0,
+                               int(plan.n_items))
 
     def D_in_model_order(self):
         """D[u, s] indexed like the model's random_ind (the sliced pass keeps every user's negatives sorted by item)."""

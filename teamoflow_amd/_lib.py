@@ -33,7 +33,8 @@ class SliceLists(ctypes.Structure):
     _fields_ = [('R_sorted', ctypes.c_void_p), ('slice_off', ctypes.c_void_p), ('rowptr', ctypes.c_void_p),
                 ('col', ctypes.c_void_p), ('pos_off', ctypes.c_void_p), ('n_users', ctypes.c_int32),
                 ('n_samples', ctypes.c_int32), ('n_slices', ctypes.c_int32), ('slice_begin', ctypes.c_int32),
-                ('slice_count', ctypes.c_int32), ('item_base', ctypes.c_int32), ('xcd_major', ctypes.c_int32)]
+                ('slice_count', ctypes.c_int32), ('item_base', ctypes.c_int32), ('xcd_major', ctypes.c_int32),
+                ('n_items', ctypes.c_int32)]
 
 
 class Segments(ctypes.Structure):
@@ -114,7 +115,7 @@ for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_scores5', 'tmf_wmrb_gradu3', 'tmf_wm
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name + '_f32']
 
 _lib = None
-MIN_LIB_VERSION = 202   # include/tmf.h TMF_VERSION: 202 = tmf_slice_lists grew to 72 bytes (xcd_major) + the round-3 entry points
+MIN_LIB_VERSION = 202   # include/tmf.h TMF_VERSION: 202 = tmf_slice_lists is 80 bytes (xcd_major, n_items) + the round-3 entry points
 
 
 def build(force=False, verbose=False):

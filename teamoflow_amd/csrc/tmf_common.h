@@ -350,6 +350,28 @@ struct Reduce8x32 {
     }
 };
 
+// The same for FOUR partial sums (10 instructions): afterwards lane l holds the sum of entry ((l >> 4) & 1) | ((l >> 2) & 2), every
+// entry on 8 lanes.  Four rows in flight keep the scores kernel at 8 waves per SIMD (eight cost it two of them: profiles/r04_*).
+struct Reduce4x32 {
+    static __device__ __forceinline__ int entry_of_lane(int lane) { return ((lane >> 4) & 1) | ((lane >> 2) & 2); }
+    static __device__ __forceinline__ bool owner(int lane) { return (lane & 7) == 0; }
+    static __device__ __forceinline__ float run(const float (&p)[4], int lane) {
+        float q[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const auto s = __builtin_amdgcn_permlane16_swap(__float_as_int(p[2 * i]), __float_as_int(p[2 * i + 1]), false, false);
+            q[i] = __int_as_float(s[0]) + __int_as_float(s[1]);
+        }
+        q[0] += TMF_DPP_MOV(q[0], 0x128);
+        q[1] += TMF_DPP_MOV(q[1], 0x128);
+        float r = (lane & 8) ? q[1] : q[0];
+        r += TMF_DPP_MOV(r, 0xB1);
+        r += TMF_DPP_MOV(r, 0x4E);
+        r += TMF_DPP_MOV(r, 0x141);
+        return r;
+    }
+};
+
 // Row stores.  Every row this engine writes (new table rows, slab partials, raw gradients, per-slice partials) is written
 // once and read by a LATER kernel, so the stores carry the non-temporal hint.  Measured on one box, same run: the hint
 // itself changes nothing (item pass at C4 36.8 ms without, 36.6 ms with); what took that kernel from 44.0 to 36.8 ms was

@@ -451,6 +451,48 @@ __device__ __forceinline__ void slice_list(int* ids, float* dst, const int32_t* 
     }
 }
 
+// The scores walk of slice_list in a leaner form for rows of 32 lanes whose table is addressable with 32-bit byte offsets
+// (SliceLists::lean): four rows per step as before, but ONE instruction per row address (load_raw32), the dot product on packed
+// pairs (dot_raw), the four scores of a step reduced together (Reduce4x32: 10 instructions instead of 4 x 7) and stored by four
+// lanes, no compare / select per entry - the tail of a tile points at the resident row `safe` from the moment it is staged.
+// Scores agree with the general form to rounding (another summation tree), exactly on dyadic data.
+template <int NV, typename T>
+__device__ __forceinline__ void slice_scores_lean(int* ids, const int32_t* __restrict__ list, int beg, int end, const T* __restrict__ V,
+                                                  const Raw<NV, T>& x, float* __restrict__ out, int g, int lane, int safe) {
+    constexpr int G = 32, kStageTile = Stage<G>::tile;
+    const uint32_t loff = 16u * (uint32_t)g;
+    const int my_entry = Reduce4x32::entry_of_lane(lane);
+    // every entry of a step ends up on 8 lanes: lane l keeps the score of step (l & 7) of a block of eight steps, so that after
+    // eight steps the 32 lanes hold 32 consecutive scores and leave in ONE 128-byte store (16-byte stores per step cost the kernel
+    // 4 ms at C4: partial lines)
+    const int my_step = lane & 7, my_slot = 4 * my_step + my_entry;
+    for (int t0 = beg; t0 < end; t0 += kStageTile) {
+        const int cnt = (end - t0 < kStageTile) ? end - t0 : kStageTile;
+        const int cnt4 = (cnt + 3) & ~3;
+        for (int e = g; e < cnt4; e += G) ids[e] = e < cnt ? (kStreamNT ? __builtin_nontemporal_load(list + t0 + e) : list[t0 + e]) : safe;
+        wave_lds_sync();
+        float keep = 0.f;
+        for (int e0 = 0; e0 < cnt4; e0 += 4) {
+            const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);
+            Raw<NV, T> y[4];
+            load_raw32<G, NV>(y[0], V, (uint32_t)id4.x, loff);
+            load_raw32<G, NV>(y[1], V, (uint32_t)id4.y, loff);
+            load_raw32<G, NV>(y[2], V, (uint32_t)id4.z, loff);
+            load_raw32<G, NV>(y[3], V, (uint32_t)id4.w, loff);
+            float pr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pr[t] = dot_raw<NV>(x, y[t]);
+            const float sc = Reduce4x32::run(pr, lane);
+            const int step = (e0 >> 2) & 7;
+            keep = (step == my_step) ? sc : keep;
+            if (step == 7 || e0 + 4 >= cnt4) {   // a full block of 32 scores, or the tail of the tile
+                const int at = (e0 & ~31) + my_slot;
+                if (at < cnt) __builtin_nontemporal_store(keep, out + t0 + at);
+            }
+        }
+    }
+}
+
 // Arguments shared by the two slice kernels: the per-user sorted negatives with their slice offsets, and the CSR of the
 // interactions (sorted by item inside a user) with theirs.
 struct SliceLists {
@@ -465,6 +507,7 @@ struct SliceLists {
     int sl0, nsl;            // slices [sl0, sl0 + nsl) are covered by this launch ...
     int item_base;           // ... and V points at item row item_base (windowed V: only these rows are resident)
     int xcd;                 // 1: XCD-major block order (slice_of_block)
+    int lean;                // 1: V is addressable with 32-bit byte offsets (tmf_slice_lists.n_items says so): slice_scores_lean
 };
 
 // Which (slice, user group) a block works on.  Plain order is slice-major: every resident workgroup walks the SAME slice, so
@@ -505,6 +548,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_wmrb_scores3(SliceLists a, const
     const int64_t ubeg = grp * a.upg;
     const int64_t uend = (ubeg + a.upg < a.n_users) ? ubeg + a.upg : a.n_users;
     V = window_base<G, NV, T>(V, a.item_base);
+    if constexpr (G == 32 && sizeof(Raw<NV, T>) <= 16) {
+        if (a.lean) {
+            for (int64_t u = ubeg + gid; u < uend; u += NGB) {
+                const int64_t o = u * (a.n_slices + 1) + sl;
+                const int nb = a.off[o], ne = a.off[o + 1], pb = a.poff[o], pe = a.poff[o + 1];
+                if (nb == ne && pb == pe) continue;
+                Raw<NV, T> x;   // the user's own row as stored: read once per (user, slice) visit
+                {
+                    const char* xp = reinterpret_cast<const char*>(U) + u * (int64_t)RowBytes<G, NV, T>::value + 16 * g;
+                    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) x.v[v] = load_f4_nt(reinterpret_cast<const float*>(xp + 16 * G * v));
+                    } else {
+#pragma unroll
+                        for (int pv = 0; pv < NV / 2; ++pv) x.v[pv] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xp + 16 * G * pv));
+                    }
+                }
+                slice_scores_lean<NV, T>(ids, a.R + u * (int64_t)a.S, nb, ne, V, x, sp + u * (int64_t)a.S, g, lane, a.item_base);
+                const int64_t rb = a.rowptr[u];
+                slice_scores_lean<NV, T>(ids, a.col + rb, pb, pe, V, x, p + rb, g, lane, a.item_base);
+            }
+            return;
+        }
+    }
     for (int64_t u = ubeg + gid; u < uend; u += NGB) {
         const int64_t o = u * (a.n_slices + 1) + sl;
         const int nb = a.off[o], ne = a.off[o + 1], pb = a.poff[o], pe = a.poff[o + 1];
@@ -796,7 +863,7 @@ extern "C" int tmf_wmrb_user_pass_bf16(const int64_t* rowptr, const int32_t* col
 }
 
 // ---- sliced pass: storage-type generic implementations + the _f32 / _bf16 entry points ----
-static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what, int lanes_per_row, int waves) {
+static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what, int lanes_per_row, int waves, size_t row_bytes = 0) {
     TMF_REQUIRE(l != nullptr, "%s: lists is null", what);
     TMF_REQUIRE(l->n_users >= 0 && l->n_slices > 0 && l->n_samples > 0, "%s: n_users=%d n_slices=%d n_samples=%d", what,
                 l->n_users, l->n_slices, l->n_samples);
@@ -816,8 +883,12 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
                 what, sl0, l->slice_count, l->n_slices, l->item_base);
     int xcd = l->xcd_major != 0;
     if (const char* env = getenv("TMF_SLICE_XCD")) xcd = env[0] == '1';   // A/B runs
+    // the lean scores walk addresses V with 32-bit byte offsets: only when the caller says how many items there are (n_items = 0:
+    // not stated) and they fit; TMF_LEAN=0 forces the general form (A/B runs, tests)
+    int lean = l->n_items > 0 && row_bytes > 0 && (int64_t)l->n_items * (int64_t)row_bytes < ((int64_t)1 << 32);
+    if (const char* env = getenv("TMF_LEAN")) lean = lean && env[0] != '0';
     a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups,
-                   upg, sl0, nsl, l->item_base, xcd};
+                   upg, sl0, nsl, l->item_base, xcd, lean};
     return TMF_OK;
 }
 
@@ -846,7 +917,7 @@ static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const 
     SliceLists a;
     const RowGeom geom = row_geom_of<T>(n_components);
     const int waves = slice_waves(lists, geom.G);
-    if (int rc = check_lists(lists, a, "wmrb_scores3", geom.G, waves)) return rc;
+    if (int rc = check_lists(lists, a, "wmrb_scores3", geom.G, waves, (size_t)geom.ld * sizeof(T))) return rc;
     if (a.n_users == 0) return TMF_OK;
     TMF_REQUIRE(U && V && sp && (p || lists->col == nullptr), "wmrb_scores3: null pointer");
     const size_t lds = slice_lds(geom, waves);

@@ -150,3 +150,26 @@ def test_scores5_pacing_changes_nothing(eng, monkeypatch, lag):
     assert np.array_equal(ws[:, -1], np.diff(s5.wg_ptr.cpu().numpy()) // 8)
     for k in ('sp', 'pk', 'U', 'V'):
         assert torch.equal(a[k], free[k]) and torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('dtype,r', [(torch.float32, 128), (torch.float32, 70), (torch.bfloat16, 256)])
+def test_lean_scores_walk_equals_the_general_form(eng, monkeypatch, dtype, r):
+    """tmf_wmrb_scores3 walks a (user, slice) range in a leaner form when tmf_slice_lists.n_items says V is addressable with 32-bit
+    offsets (rows of 32 lanes): one instruction per row address, packed dot products, four scores reduced together.  Against the
+    general form (TMF_LEAN=0): bit for bit on dyadic tables - and then the whole epoch is - and to rounding on Gaussian ones."""
+    m, n, S, nnz = 3000, 9000, 100, 60000
+    for dyadic in (True, False):
+        idx, val, R, U, V = problem(m, n, r, S, nnz, seed=31 + r, dyadic=dyadic)
+        monkeypatch.setenv('TMF_LEAN', '0')
+        a = epoch(eng, monkeypatch, False, idx, val, R, U, V, m, n, r, S, dtype, 5)
+        monkeypatch.setenv('TMF_LEAN', '1')
+        b = epoch(eng, monkeypatch, False, idx, val, R, U, V, m, n, r, S, dtype, 5)
+        if dyadic:
+            for k in ('sp', 'pk', 'D', 'delta', 'U', 'V'):
+                assert torch.equal(a[k], b[k]), (k, r)
+            assert a['loss'] == b['loss']
+        else:
+            scale = float(a['sp'].abs().max())
+            assert float((a['sp'] - b['sp']).abs().max()) <= 2e-6 * scale and float((a['pk'] - b['pk']).abs().max()) <= 2e-6 * scale
+            assert abs(a['loss'] - b['loss']) <= 1e-6 * abs(a['loss'])
+            assert not torch.equal(a['sp'], b['sp'])    # another summation tree: the lean form really ran
