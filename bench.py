@@ -39,6 +39,8 @@ HBM_COPY_MEASURED = 6.29e12                # the guide's measured float4 copy fr
 FABRIC_GATHER_MEASURED = 8.6e12            # the guide's measured rate of row gathers served by the Infinity Cache (38 MB table)
 FABRIC_BOUND_FROM = 0.75                   # measured fabric traffic from this share of the HBM peak on = the kernel is bound there
 FABRIC_LABEL = 'fabric (L2-miss traffic incl. Infinity-Cache hits)'
+FABRIC_LABEL_FROM = 6.5e12                 # measured fabric rate from which a kernel is priced on the fabric roof: clearly above the ~6.3 TB/s an
+                                           # HBM copy reaches (a streaming kernel AT that ceiling - the combine: 6.3 TB/s, L2 hit rate 0.01 - is HBM-bound)
 
 
 def log(*a):
@@ -235,7 +237,7 @@ def roofline_report(models, prof, pmc=None):
             # 0.41, 7 - 9 TB/s of fabric traffic - at or above the measured copy ceiling): price the kernel where it is bound.
             # (The C4 item pass moves 4.5 TB/s over the fabric - 0.56 of the peak, more than its L2 fraction, but nowhere near a
             # roof: it stays on the L2 roof it is built against.)
-            if rate > HBM_COPY_MEASURED:
+            if rate > FABRIC_LABEL_FROM:
                 fabric(f"; blocked for the L2s (gather rate {e['gather_rate_GBps'] / 1e3:.1f} TB/s = {e['l2_frac']:.2f} of the L2 roof)")
             else:
                 e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=rate / HBM_PEAK, frac_source='pmc',
@@ -246,7 +248,7 @@ def roofline_report(models, prof, pmc=None):
         elif k['roof'] == 'hbm' and meas is not None:
             # HBM-bound kernel with counters of this code version: the fraction is MEASURED fabric bytes (L2 misses + writes,
             # FETCH_SIZE / WRITE_SIZE) over the kernel's time - not the byte model
-            if rate > HBM_COPY_MEASURED:
+            if rate > FABRIC_LABEL_FROM:
                 fabric()
             else:
                 e.update(bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9, frac=rate / HBM_PEAK, frac_source='pmc')
