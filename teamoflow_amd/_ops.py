@@ -64,8 +64,13 @@ def _bf16_operand(t):
 
 
 def fused_topk_supported(user_embedding, item_embedding, k):
+    """Whether predict_topk ranks these tables without materialising scores: k <= 64, width <= 256 (bf16 tables beyond the bf16 kernel's
+    k <= 32 go through the fp32 fused kernel on exact fp32 copies: predict_topk)."""
     bf16 = user_embedding.dtype == torch.bfloat16 and item_embedding.dtype == torch.bfloat16
-    return k <= (FUSED_MAX_K_BF16 if bf16 else FUSED_MAX_K) and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
+    return k <= FUSED_MAX_K and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
+
+
+BF16_UPCAST_USERS = 1 << 18   # users per call when bf16 tables are ranked through the fp32 kernel (bounds the fp32 copy of their rows)
 
 
 PREDICT_ARITHMETIC = os.environ.get('TMF_PREDICT_ARITHMETIC', 'auto')   # 'auto' | 'fp32' | 'split' | 'half2'
@@ -104,7 +109,7 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     factor, three products, ~2.9x; one scale for the whole item table, so check half2_range_ok(item_embedding) first.
     Scores BEYOND the fp32 range: the fp32 kernel returns +-inf like tf.matmul; the plane kernels may form +inf - inf = NaN between
     plane products of opposite sign, and a NaN score is never ranked (the ids returned are those of the finite scores).
-    bf16 tables (both operands): bf16 MFMA with fp32 accumulation, k <= 32, width <= 256.
+    bf16 tables (both operands): bf16 MFMA with fp32 accumulation, k <= 32, width <= 256; 32 < k <= 64: the fp32 kernel on exact fp32 copies.
     See topk_stable(predict_gemm(...)) for the general case."""
     lib = _lib.get()
     arithmetic = arithmetic or PREDICT_ARITHMETIC
@@ -119,6 +124,19 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
         k = int(k)
         if not 1 <= k <= n:
             raise ValueError(f'k={k} must be in [1, {n}]')
+        if FUSED_MAX_K_BF16 < k <= FUSED_MAX_K:
+            # The bf16 kernel keeps 256 users' lists in LDS: k <= 32.  Beyond it the fp32 fused kernel (k <= 64) ranks exact fp32
+            # copies of the rows - a bf16 x bf16 product is exact in fp32 either way, the fp32 sums differ in order only.
+            Bf = B.float()
+            out_i, out_v = [], []
+            for b in range(0, m, BF16_UPCAST_USERS):
+                r_ = predict_topk(A[b:b + BF16_UPCAST_USERS].float(), Bf, k, clamp_negatives=clamp_negatives, return_values=return_values,
+                                  arithmetic='fp32')
+                out_i.append(r_[1] if return_values else r_)
+                if return_values:
+                    out_v.append(r_[0])
+            idx = torch.cat(out_i) if len(out_i) > 1 else out_i[0]
+            return ((torch.cat(out_v) if len(out_v) > 1 else out_v[0]), idx) if return_values else idx
         idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
         vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
         _lib.check(lib.tmf_predict_topk_bf16(_lib.ptr(A), _lib.ptr(B), m, n, r, lda, ldb, k, int(bool(clamp_negatives)),

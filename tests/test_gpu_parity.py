@@ -870,7 +870,7 @@ def test_randomized_fused_topk(tm, seed):
     ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
     got = tm.ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp).cpu().numpy()
     assert np.array_equal(got, ref), (m, n, r, k, clamp, 'f32')
-    if k <= tm.ops.FUSED_MAX_K_BF16:
+    if k <= tm.ops.FUSED_MAX_K:   # bf16 tables: the bf16 kernel up to k = 32, beyond it the fp32 kernel on exact fp32 copies (_ops.predict_topk)
         gb = tm.ops.predict_topk(torch.tensor(U).to(torch.bfloat16).cuda(), torch.tensor(V).to(torch.bfloat16).cuda(), k,
                                  clamp_negatives=clamp).cpu().numpy()
         assert np.array_equal(gb, ref), (m, n, r, k, clamp, 'bf16')
