@@ -313,7 +313,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
     // bound of the row's final k-th value.  The scan then restarts at tile 0 with every threshold just below that bound:
     // the rows skip the phase in which nearly every score is a candidate (half of all k (1 + ln(n / k)) insertions of a row
     // fall into its first ~5 tiles) for warm / ntiles (<= 1/64) more MFMA work.
-    const int warm = (k <= 24 && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
+#ifndef TMF_SPLIT_WARM_MAXK
+#define TMF_SPLIT_WARM_MAXK 32   /* round 4: 24 -> 32 (k = 25: 130.7 -> 134.6 TF, k = 28: 119.6 -> 123.6, k = 32 unchanged; same box) */
+#endif
+    const int warm = (k <= TMF_SPLIT_WARM_MAXK && ntiles >= 256) ? (ntiles / 64 < 128 ? ntiles / 64 : 128) : 0;
     const int warm_chunks = warm * NCH;
     const int64_t plane = n_pad * LDP;
     auto g_issue = [&](int g, int slot) {   // chunk g -> ring slot `slot` (three LDS-DMA loads per wave)
