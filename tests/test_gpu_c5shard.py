@@ -135,6 +135,5 @@ def test_c5_shard_fused_topk_on_trained_tables(c5):
     st, r = c5['st'], c5['r']
     U, V = st.U_nxt[:256, :r], st.V_nxt[:, :r]
     vals, idx = _ops.predict_topk(U, V, 10, return_values=True)
-    # one near-sign Adam step from a global-L2-normalised start leaves factors of almost equal magnitude, i.e. many (near-)equal
-    # scores: no share of index-identical rows is demanded here (the full-catalog test demands 97 % on random tables)
-    check_topk_against_cpu_oracle(U, V, vals, idx, 10, min_identical_rows=0.0)
+    # measured in round 4: every one of the 256 rows identical index for index (97.7 % of them have clear gaps): the default bound (97 %)
+    check_topk_against_cpu_oracle(U, V, vals, idx, 10)

@@ -197,6 +197,7 @@ def check_topk_against_cpu_oracle(U, V, vals, idx, k, min_identical_rows=0.97):
     assert bool(clear.any())
     assert torch.equal(got_i[clear], want_i[clear, :k])
     identical = float((got_i == want_i[:, :k]).all(dim=1).float().mean())
+    print(f'[top-k vs CPU oracle] rows identical index for index: {identical:.4f}; rows with clear gaps: {float(clear.float().mean()):.4f}')
     assert identical >= min_identical_rows, (identical, float(clear.float().mean()))
     picked = torch.gather(S, 1, got_i)
     assert rel_err(picked.numpy(), want_v[:, :k].numpy()) < 1e-5
