@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: started WITHOUT a launcher (no WORLD_SIZE in the environment) `--gpus N` starts its own ranks -
+`python -m torch.distributed.run --standalone --nproc-per-node N bench.py ...` as a CHILD process, before this process has made
+any GPU call (`spawn_ranks`; a process that has initialised the GPU must never exec another program on this pool) -
+relays rank 0's JSON line and exits with the child's code.
+
 A "step" is one full-batch training epoch (user pass + item pass + fresh-Adam updates + loss), the
 unit the reference times at matrix_factorization.py:129-177.  Workload = BASELINE.json's metric
 configuration: 1M users x 100K items, r = 128, WMRB with S = 1024 static negatives, ~1e8 interactions
@@ -344,6 +349,19 @@ def host_cores():
     return min(n, 16) if n > 64 else n
 
 
+def baseline_sample(idx, val, users, n):
+    """The interactions of users 0 .. users-1 as host arrays.  Selected COLUMN BY COLUMN (_engine.take_interactions):
+    row-indexing a [1e8, 2] int64 device tensor with a mask returns wrong rows on this PyTorch-ROCm build - the count
+    would still look right.  The sample is checked: every user below `users`, every item below n, unique row-major order kept."""
+    sidx, sval = (t.cpu().numpy() for t in _engine.take_interactions(idx, val, idx[:, 0] < users))
+    if len(sval):
+        key = sidx[:, 0].astype(np.int64) * n + sidx[:, 1]
+        if sidx.shape[0] != len(sval) or sidx.min() < 0 or int(sidx[:, 0].max()) >= users or int(sidx[:, 1].max()) >= n \
+                or not bool(np.all(np.diff(key) > 0)):
+            raise AssertionError('cpu_baseline: the selected interactions are not the row-major prefix of the workload')
+    return sidx, sval
+
+
 def cpu_baseline(loss, idx, val, R, U0, V0, n, S, lr, users=None, epochs=3):
     """The C/OpenMP closed-form epoch (oracle/sparse_ref.c - "sparse CPU restatement, not the reference
     formulation") on the first `users` users of the same workload with every host core this
@@ -352,8 +370,7 @@ def cpu_baseline(loss, idx, val, R, U0, V0, n, S, lr, users=None, epochs=3):
     cores = host_cores()
     sparse_c.set_threads(cores)
     users = min(users or (131072 if loss == 'wmrb' else 262144), int(U0.shape[0]))   # ~10-20 s of CPU work at C4 on 16 cores
-    rows = idx[:, 0] < users
-    sidx, sval = idx[rows].cpu().numpy(), val[rows].cpu().numpy()
+    sidx, sval = baseline_sample(idx, val, users, n)
     Us, Vs = U0[:users].cpu().numpy(), V0.cpu().numpy()
     plan = sparse_c.Plan(sidx, sval, users, n, R[:users].cpu().numpy() if loss == 'wmrb' else None)
 
@@ -850,6 +867,50 @@ def sharded_run(args, rank, world, dev, rehearse, red_dev, json_out):
     print(compact_line(out), file=json_out, flush=True)
 
 
+def launcher_command(n, argv, port=None):
+    """The command line of the N ranks of `bench.py --gpus N` (one process per GPU over RCCL; the reference has no launcher:
+    /root/reference/src/teamoflow/mf/matrix_factorization.py:96 is one process).  127.0.0.1 rendezvous: a container's hostname may not resolve."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the ranks as a CHILD process,
+    pass rank 0's JSON line through and return the child's exit code.  Nothing in this process has touched the GPU at this
+    point and nothing will (no torch.cuda call, no _lib.get()): the parent only waits.  Returns None when this process IS a
+    rank (or N = 1) and should run the bench itself."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return None
+    import subprocess
+    rehearse = os.environ.get('TMF_BENCH_REHEARSE') == '1'
+    have = torch.cuda.device_count()   # counts devices without initialising the GPU on this image
+    if have < args.gpus and not rehearse:
+        raise SystemExit(f'--gpus {args.gpus} but this node shows {have} GPU(s) (TMF_BENCH_REHEARSE=1 puts all ranks on card 0 for a functional rehearsal)')
+    assert not torch.cuda.is_initialized(), 'the launcher process must not have initialised the GPU'
+    cmd = launcher_command(args.gpus, argv)
+    log('[bench] no launcher around --gpus %d: starting %s' % (args.gpus, ' '.join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in child.stdout if ln.strip()]
+    rc = child.wait()
+    found = [ln for ln in lines if ln.lstrip().startswith('{"metric"')]
+    for ln in lines:   # anything else a rank wrote to stdout goes to stderr: the contract is ONE line on stdout
+        if ln not in found[-1:]:
+            log(ln.rstrip())
+    if found:
+        sys.stdout.write(found[-1] if found[-1].endswith('\n') else found[-1] + '\n')
+        sys.stdout.flush()
+    elif rc == 0:
+        log('[bench] the ranks exited 0 without a JSON line')
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -875,6 +936,9 @@ def main():
                          '(dist.ItemShardedEpoch) instead of the replicated table; one JSON line with an epoch-level roofline entry')
     ap.add_argument('--no-legs', action='store_true', help='skip the two HBM-streaming side legs (C4 MSE, config-5 shard)')
     args = ap.parse_args()
+    rc = spawn_ranks(args, sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
 
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner at communicator
     # creation) write to file descriptor 1 as well, so keep a private copy of stdout for the JSON line and point
@@ -887,7 +951,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but the launcher set WORLD_SIZE={world}: start it with --nproc-per-node {args.gpus}, or '
+                         'without a launcher (bench.py then starts its own ranks)')
     # TMF_BENCH_REHEARSE=1: every rank on card 0 with a gloo group (dist.py stages the collectives through the host) -
     # a functional rehearsal of the N>1 path on a one-GPU box; its timings mean nothing
     rehearse = os.environ.get('TMF_BENCH_REHEARSE') == '1'

@@ -103,6 +103,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
 // neighbouring lists are served by ONE L2 - changed nothing: 32.8 vs 32.6 ms at C4, profiles/r02_hinge_rewrite.txt.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kWsumTile = 512;  // entries a wave stages in LDS per step (ids + weights: 4 KB per wave)
+#ifndef TMF_WSUM_VARIANT
+#define TMF_WSUM_VARIANT 0   // 1 / 2: timing-only builds that split the item pass's time (tools/build_variant.sh; profiles/r05_item_pass_split.txt)
+#endif
+#ifndef TMF_WSUM_OCC
+#define TMF_WSUM_OCC   // e.g. -DTMF_WSUM_OCC='__attribute__((amdgpu_waves_per_eu(8,8)))' for an occupancy experiment
+#endif
+#ifndef TMF_WSUM_INNER
+#define TMF_WSUM_INNER 1     // 1: vector LDS reads + select (round 5); 0: scalar LDS reads and a branch per entry (rounds 1-4)
+#endif
 
 template <int G, int NV, typename T>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
@@ -172,13 +181,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass(
 // 32.6 ms, C4 bf16 27.8 -> 25.0 ms.  Used for rows of 16 lanes or more (narrower rows would leave each group a tile of
 // a few dozen staged entries); TMF_WSUM_PER_GROUP=0 selects k_wsum_pass for A/B runs.
 template <int G, int NV, typename T>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
+__global__ __launch_bounds__(64 * kWavesPerBlock) TMF_WSUM_OCC void k_wsum_pass_pg(
     SegView sv, const int32_t* __restrict__ ent_row, const int32_t* __restrict__ ent_w,
     const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
     void* __restrict__ X_out, float* __restrict__ slab, int epi, tmf_adam adam) {
     constexpr int NG = 64 / G, TILE = kWsumTile / NG;
-    __shared__ int s_ids[kWavesPerBlock][kWsumTile];
-    __shared__ float s_w[kWavesPerBlock][kWsumTile];
+    __shared__ __attribute__((aligned(16))) int s_ids[kWavesPerBlock][kWsumTile];
+    __shared__ __attribute__((aligned(16))) float s_w[kWavesPerBlock][kWsumTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane & (G - 1), grp = lane / G;
     // XCD-contiguous block order (sv.xcd_run > 0; speed only): blocks b and b + 8 share an XCD under the observed round-robin
@@ -209,10 +218,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
     for (int64_t t0 = beg; t0 < end; t0 += TILE) {
         const int cnt = (int)((end - t0 < TILE) ? end - t0 : TILE);
         for (int e = g; e < cnt; e += G) {   // (non-temporal loads of the entry lists were measured: 30.65 -> 32.7 ms; not used)
+#if TMF_WSUM_VARIANT == 1   // timing only: weight derived from the streamed entry, no 4-byte gather
+            ids[e] = ent_row[t0 + e];
+            ws[e] = __int_as_float(0x3f800000 | (ent_w[t0 + e] & 0xffff));
+#elif TMF_WSUM_VARIANT == 2   // timing only: sixteen L1-resident rows, no row gather from the L2s
+            ids[e] = ent_row[t0 + e] & 15;
+            ws[e] = wbuf[ent_w[t0 + e]];
+#elif TMF_WSUM_VARIANT == 3   // timing only: neither gather - streams, LDS, arithmetic and the partial-row stores remain
+            ids[e] = ent_row[t0 + e] & 15;
+            ws[e] = __int_as_float(0x3f800000 | (ent_w[t0 + e] & 0xffff));
+#else
             ids[e] = ent_row[t0 + e];
             ws[e] = wbuf[ent_w[t0 + e]];
+#endif
         }
         wave_lds_sync();
+#if TMF_WSUM_INNER == 0
         for (int e0 = 0; e0 < cnt; e0 += kUnroll) {
             Raw<NV, T> raw[kUnroll];
             float wc[kUnroll];
@@ -234,6 +255,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_wsum_pass_pg(
                 axpy<NV>(acc, wc[t], y);
             }
         }
+#else
+        // the four ids and the four weights of a step in ONE LDS read each (16-byte aligned tile, e0 % 4 == 0; slots past cnt hold
+        // stale values and are never used), the four row loads issued back to back, a zero weight (or a slot past the list) as a
+        // select to the tile's first row - an L1 hit multiplied by 0 - instead of a branch around the load
+        static_assert(kUnroll == 4 && TILE % 4 == 0, "vector LDS reads assume four entries per step");
+        const int safe = ids[0];
+        for (int e0 = 0; e0 < cnt; e0 += 4) {
+            const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);
+            const float4 w4 = *reinterpret_cast<const float4*>(ws + e0);
+            const int idv[4] = {id4.x, id4.y, id4.z, id4.w};
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            Raw<NV, T> raw[4];
+            float wc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool want = e0 + t < cnt && wv[t] != 0.f;
+                wc[t] = want ? wv[t] : 0.f;
+                load_raw<G, NV>(raw[t], Tab, want ? idv[t] : safe, g);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Frag<NV> y;
+                to_frag<NV>(y, raw[t]);
+                axpy<NV>(acc, wc[t], y);
+            }
+        }
+#endif
     }
     if (live) {
         const int slot = sv.seg_slab[seg];

@@ -158,3 +158,80 @@ def test_strong_partition_is_balanced_on_drawn_degrees(bench):
     real = torch.bincount(idx[:, 0], minlength=m)
     cost = [int(real[b:e].sum()) + 64 * (e - b) for b, e in zip(bounds[:-1], bounds[1:])]
     assert max(cost) < 1.05 * (sum(cost) / 8), cost     # cut on DRAWN degrees, balanced on the realised (unique) ones to a few %
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks_before_any_gpu_call(bench, monkeypatch, capsys):
+    """the driver runs plain `python3 bench.py --gpus N`.  The parent must build the torch.distributed.run
+    command, start it as a CHILD, relay rank 0's line and exit with the child's code - without a single GPU call of its own
+    (a process that has initialised the GPU must never start another program by exec on this pool)."""
+    import argparse
+    import subprocess
+    import torch
+
+    def boom(*a, **k):
+        raise AssertionError('GPU call in the launcher process')
+    for name in ('set_device', 'synchronize', 'init', 'current_device', 'get_device_properties'):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(bench._lib, 'get', boom)
+    monkeypatch.setattr(bench._lib, 'load_library', boom)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('TMF_BENCH_REHEARSE', raising=False)
+    seen = {}
+
+    class Child:
+        def __init__(self, cmd, stdout=None, env=None, text=None):
+            seen.update(cmd=cmd, env=env, stdout=stdout)
+            self.stdout = iter(['NCCL version 2.x banner\n', '{"metric":"train_interactions_per_sec","n_gpus":4}\n'])
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(subprocess, 'Popen', Child)
+    argv = ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=4), argv)
+    assert rc == 0
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nproc-per-node=4' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-len(argv):] == argv
+    assert os.path.samefile(cmd[-len(argv) - 1], os.path.join(ROOT, 'bench.py'))
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and seen['stdout'] == subprocess.PIPE
+    out = capsys.readouterr()
+    assert out.out == '{"metric":"train_interactions_per_sec","n_gpus":4}\n'      # ONE line on stdout, the banner went to stderr
+    assert 'banner' in out.err
+    # a failing child: its code is the parent's
+    Child.wait = lambda self: 3
+    assert bench.spawn_ranks(argparse.Namespace(gpus=4), argv) == 3
+    # this process IS a rank (launcher around it) or N = 1: run the bench here
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    assert bench.spawn_ranks(argparse.Namespace(gpus=4), argv) is None
+    monkeypatch.delenv('WORLD_SIZE')
+    assert bench.spawn_ranks(argparse.Namespace(gpus=1), ['--gpus', '1']) is None
+    # fewer cards than ranks: a clear refusal, not eight ranks fighting over one card
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    with pytest.raises(SystemExit, match='shows 1 GPU'):
+        bench.spawn_ranks(argparse.Namespace(gpus=4), argv)
+
+
+def test_importing_bench_and_parsing_arguments_initialises_no_gpu():
+    """The launcher path of `python bench.py --gpus N` runs in a fresh interpreter: importing bench.py must not touch the GPU."""
+    import subprocess
+    code = ("import sys, torch; sys.argv=['bench.py']; import bench; "
+            "assert not torch.cuda.is_initialized() and bench._lib._lib is None; print('ok')")
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+
+
+def test_cpu_baseline_sample_is_selected_column_by_column(bench, monkeypatch):
+    """the baseline's sample went through `idx[mask]` on the [1e8, 2] int64 list - the row-indexing trap of
+    this PyTorch-ROCm build.  It goes through _engine.take_interactions now and the sample is checked."""
+    calls = []
+    real = bench._engine.take_interactions
+    monkeypatch.setattr(bench._engine, 'take_interactions', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    idx, val = bench.gen_interactions(300, 50, 3000, 'zipf', 0, 'cpu')
+    sidx, sval = bench.baseline_sample(idx, val, 100, 50)
+    assert calls and sidx[:, 0].max() < 100 and len(sval) == int((idx[:, 0] < 100).sum())
+    assert np.array_equal(sidx, idx[: len(sval)].numpy())
+    # rows that are not the prefix (what the trap returns: right count, wrong rows) are refused
+    monkeypatch.setattr(bench._engine, 'take_interactions', lambda i, v, keep, **k: (i[-int(keep.sum()):], v[-int(keep.sum()):]))
+    with pytest.raises(AssertionError, match='row-major prefix'):
+        bench.baseline_sample(idx, val, 100, 50)
