@@ -17,6 +17,9 @@ Reference lines followed (all under /root/reference/src/teamoflow/mf/):
   loss_graphs.py:36-52            MSELoss.get_loss
   loss_graphs.py:62-88            WMRBLoss.get_loss
   embedding_graphs.py:30-38       LinearEmbedding.get_repr
+  embedding_graphs.py:41-58       BiasedLinearEmbedding.get_repr   (fit_dense_plugins)
+  embedding_graphs.py:61-87       ReLUEmbedding.get_repr           (fit_dense_plugins)
+  loss_graphs.py:91-122           KLDivergenceLoss.get_loss        (kl_loss; normal CDF as tensorflow-probability's ndtr)
   initializer_graphs.py:27-52     Normal/UniformInitializer (global l2_normalize)
   utils.py:62-105                 gather_matrix_indices
 TensorFlow semantics restated (TF >= 2.9, unpinned in the reference):
@@ -117,6 +120,116 @@ def wmrb_loss(indices, values, sample_predictions, prediction_serial, n_items, n
     summation = tf_maximum(1.0 - pos_pred[:, None] + mapped, 0.0)
     rank = (n_items / n_samples) * summation.sum(dim=1)
     return torch.log(1.0 + rank)
+
+
+def tfp_ndtr(z):
+    """Normal CDF the way tensorflow-probability >= 0.17 evaluates it (special_math._ndtr; the reference's
+    `tp.distributions.Normal(...).cdf`, loss_graphs.py:120-122, is ndtr((x - loc) / scale)):
+        w = z / sqrt(2);  |w| < sqrt(1/2): (1 + erf(w)) / 2;  w > 0: 1 - erfc(w) / 2;  else erfc(-w) / 2."""
+    half_sqrt_2 = 0.5 * np.sqrt(2.0)
+    w = z * half_sqrt_2
+    a = torch.abs(w)
+    y = torch.where(a < half_sqrt_2, 1.0 + torch.erf(w), torch.where(w > 0.0, 2.0 - torch.erfc(a), torch.erfc(a)))
+    return 0.5 * y
+
+
+def tf_moments(x):
+    """tf.nn.moments(x, axes=[0]): mean and POPULATION variance mean((x - mean)^2)."""
+    mean = x.mean()
+    return mean, torch.square(x - mean).mean()
+
+
+def kl_loss(values, prediction_serial):
+    """loss_graphs.py:109-122: 1 - CDF_{N(mean_neg - mean_pos, sqrt(var_pos + var_neg))}(0) - ONE scalar for the whole epoch;
+    positives are the stored values > 0, negatives the stored values <= 0."""
+    pos_mask = values > 0.0
+    neg_mask = values <= 0.0
+    pos_mean, pos_var = tf_moments(prediction_serial[pos_mask])
+    neg_mean, neg_var = tf_moments(prediction_serial[neg_mask])
+    loc, scale = neg_mean - pos_mean, torch.sqrt(pos_var + neg_var)
+    return 1.0 - tfp_ndtr((0.0 - loc) / scale)
+
+
+def embed(kind, features, weights, relu_weight=None, relu_bias=None, linear_bias=None):
+    """embedding_graphs.py:30-87 -> (embedding, [trainables]) for kind in {'linear', 'biased', 'relu'}."""
+    if kind == 'linear':
+        return features @ weights, [weights]                                   # :38
+    if kind == 'biased':
+        return features @ weights + linear_bias, [weights, linear_bias]        # :58 (bias [1, r], broadcast over the rows)
+    if kind == 'relu':
+        hidden = torch.relu(features @ relu_weight + relu_bias)                # :85
+        return hidden @ weights, [weights, relu_weight, relu_bias]             # :87
+    raise ValueError(kind)
+
+
+def fit_dense_plugins(U0, V0, indices, values, loss, epochs, lr, user_features, item_features, user_embedding='linear',
+                      item_embedding='linear', user_relu_weight0=None, item_relu_weight0=None, random_ind=None,
+                      n_items=None, n_samples=None, dtype=torch.float32, record_epochs=()):
+    """The reference training loop (matrix_factorization.py:96-187) for ANY built-in plug-in combination:
+    embeddings 'linear' | 'biased' | 'relu' per side, loss 'mse' | 'wmrb' | 'kl'.
+
+    What the reference does that this follows:
+      * biased: the [1, r] bias is created as zeros inside get_repr at the first epoch (:53-55), kept on the model (:139-146) and
+        fed back in; ReLU: weights are [aux_dim = 5 r, r] (:117, :122), relu_bias zeros [1, aux_dim] (:82-83); the [n_features,
+        aux_dim] relu_weight is drawn from TF's RNG at first use (:80-81) - not reproducible, so it is an INPUT here;
+      * every trainable of both sides takes the same fresh Keras-Adam step (:173-176);
+      * KL: tf_prediction_serial = gather_nd(predictions, indices) (:158-160), the loss is ONE scalar, reduce_mean of it is itself.
+    Returns dict(loss=[epochs], user_vars=[...], item_vars=[...] (final, numpy), snapshots={epoch: (user_vars, item_vars)},
+    first_grads=(user, item) gradients of the first epoch, user_embedding / item_embedding of the final weights (:186-187))."""
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype).clone()   # noqa: E731
+    idx = torch.as_tensor(np.asarray(indices), dtype=torch.int64)
+    val = t(values)
+    Fu, Fv = t(user_features), t(item_features)
+    R = None if random_ind is None else torch.as_tensor(np.asarray(random_ind), dtype=torch.int64)
+    r = np.asarray(U0).shape[1]
+
+    def variables(kind, W0, relu_w0, n_features):
+        if kind == 'linear':
+            return [t(W0)]
+        if kind == 'biased':
+            return [t(W0), torch.zeros(1, r, dtype=dtype)]
+        aux = 5 * r
+        assert np.asarray(W0).shape == (aux, r) and np.asarray(relu_w0).shape == (n_features, aux)
+        return [t(W0), t(relu_w0), torch.zeros(1, aux, dtype=dtype)]
+
+    def run(kind, feats, vs):
+        if kind == 'linear':
+            return embed(kind, feats, vs[0])
+        if kind == 'biased':
+            return embed(kind, feats, vs[0], linear_bias=vs[1])
+        return embed(kind, feats, vs[0], relu_weight=vs[1], relu_bias=vs[2])
+
+    uv = variables(user_embedding, U0, user_relu_weight0, Fu.shape[1])
+    iv = variables(item_embedding, V0, item_relu_weight0, Fv.shape[1])
+    losses, snaps, first_grads = [], {}, None
+    for epoch in range(epochs):
+        for v in uv + iv:
+            v.requires_grad_(True)
+        ue, utr = run(user_embedding, Fu, uv)
+        ie, itr = run(item_embedding, Fv, iv)
+        predictions = ue @ ie.T                                                 # :149
+        if loss == 'wmrb':
+            loss_fn = wmrb_loss(idx, val, gather_matrix_indices(predictions, R), predictions[idx[:, 0], idx[:, 1]], n_items, n_samples)
+        elif loss == 'mse':
+            loss_fn = mse_loss(idx, val, predictions)
+        elif loss == 'kl':
+            loss_fn = kl_loss(val, predictions[idx[:, 0], idx[:, 1]])           # :158-160
+        else:
+            raise ValueError(loss)
+        grads = torch.autograd.grad(loss_fn.sum(), utr + itr)                   # :170-171 (gradient of the sum)
+        if first_grads is None:
+            first_grads = ([g.numpy().copy() for g in grads[:len(uv)]], [g.numpy().copy() for g in grads[len(uv):]])
+        with torch.no_grad():
+            new = [adam_fresh_step(v.detach(), g, lr) for v, g in zip(utr + itr, grads)]   # :176
+        uv, iv = new[:len(uv)], new[len(uv):]
+        losses.append(float(loss_fn.detach().mean()))                           # :179
+        if (epoch + 1) in record_epochs:
+            snaps[epoch + 1] = ([v.numpy().copy() for v in uv], [v.numpy().copy() for v in iv])
+    with torch.no_grad():
+        ue, _ = run(user_embedding, Fu, uv)
+        ie, _ = run(item_embedding, Fv, iv)
+    return dict(loss=np.asarray(losses, dtype=np.float64), user_vars=[v.numpy() for v in uv], item_vars=[v.numpy() for v in iv],
+                snapshots=snaps, first_grads=first_grads, user_embedding=ue.numpy(), item_embedding=ie.numpy())
 
 
 # --------------------------------------------------------------------------------------

@@ -110,7 +110,15 @@ constexpr int kWsumTile = 512;  // entries a wave stages in LDS per step (ids + 
 #define TMF_WSUM_OCC   // e.g. -DTMF_WSUM_OCC='__attribute__((amdgpu_waves_per_eu(8,8)))' for an occupancy experiment
 #endif
 #ifndef TMF_WSUM_INNER
-#define TMF_WSUM_INNER 1     // 1: vector LDS reads + select (round 5); 0: scalar LDS reads and a branch per entry (rounds 1-4)
+// 0 (default): scalar LDS reads and a branch around the load of a zero-weight row; 1: gradu3's form - the four ids / weights of a
+// step in one ds_read_b128 each, a select to a resident row instead of the branch.  Same box, C4 fp32 item pass (two runs each,
+// profiles/r05_item_pass_split.txt): 0 -> 30.40 / 30.40 ms, 1 -> 31.52 / 31.52 ms.  The form with fewer instructions is slower,
+// as the leaner walks of round 4 were: the pass is bound by the rows' way through the texture addresser / L1 (20.4 ms with
+// every row an L1 hit and no weight gather) and by the fabric traffic of the 4-byte weight gathers (+7 ms), not by issue.
+#define TMF_WSUM_INNER 0
+#endif
+#ifndef TMF_WSUM_UNROLL
+#define TMF_WSUM_UNROLL 4    // rows a lane group keeps in flight in k_wsum_pass_pg (A/B builds)
 #endif
 
 template <int G, int NV, typename T>
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) TMF_WSUM_OCC void k_wsum_pass_
     SegView sv, const int32_t* __restrict__ ent_row, const int32_t* __restrict__ ent_w,
     const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
     void* __restrict__ X_out, float* __restrict__ slab, int epi, tmf_adam adam) {
-    constexpr int NG = 64 / G, TILE = kWsumTile / NG;
+    constexpr int NG = 64 / G, TILE = kWsumTile / NG, kWsumUnroll = TMF_WSUM_UNROLL;
     __shared__ __attribute__((aligned(16))) int s_ids[kWavesPerBlock][kWsumTile];
     __shared__ __attribute__((aligned(16))) float s_w[kWavesPerBlock][kWsumTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,11 +242,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) TMF_WSUM_OCC void k_wsum_pass_
         }
         wave_lds_sync();
 #if TMF_WSUM_INNER == 0
-        for (int e0 = 0; e0 < cnt; e0 += kUnroll) {
-            Raw<NV, T> raw[kUnroll];
-            float wc[kUnroll];
+        for (int e0 = 0; e0 < cnt; e0 += kWsumUnroll) {
+            Raw<NV, T> raw[kWsumUnroll];
+            float wc[kWsumUnroll];
 #pragma unroll
-            for (int t = 0; t < kUnroll; ++t) {
+            for (int t = 0; t < kWsumUnroll; ++t) {
                 const int e = e0 + t;
                 wc[t] = (e < cnt) ? ws[e] : 0.f;
                 if constexpr (std::is_same<T, float>::value) {
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) TMF_WSUM_OCC void k_wsum_pass_
                 }
             }
 #pragma unroll
-            for (int t = 0; t < kUnroll; ++t) {
+            for (int t = 0; t < kWsumUnroll; ++t) {
                 Frag<NV> y;
                 to_frag<NV>(y, raw[t]);
                 axpy<NV>(acc, wc[t], y);
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) TMF_WSUM_OCC void k_wsum_pass_
         // the four ids and the four weights of a step in ONE LDS read each (16-byte aligned tile, e0 % 4 == 0; slots past cnt hold
         // stale values and are never used), the four row loads issued back to back, a zero weight (or a slot past the list) as a
         // select to the tile's first row - an L1 hit multiplied by 0 - instead of a branch around the load
-        static_assert(kUnroll == 4 && TILE % 4 == 0, "vector LDS reads assume four entries per step");
+        static_assert(TILE % 4 == 0, "vector LDS reads assume four entries per step");
         const int safe = ids[0];
         for (int e0 = 0; e0 < cnt; e0 += 4) {
             const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);

@@ -1202,7 +1202,11 @@ __global__ __launch_bounds__(64 * (kS5Waves + 1)) void k_wmrb_scores5(const int3
         };
         int cur_w = 0, next_b = paced ? wst[1] : INT32_MAX;   // the wave's window and the first step of the next one
         auto pace_to = [&](int i) {   // before the rows of round i are asked for: is the wave allowed into their window?
-            if (!paced) return;
+            // Rounds past the end (the prefetch of the loop below asks for round `rounds`) repeat the last step and are never
+            // paced, and a wave in the last window has nothing left to wait for.  (Round 4 paced them: st_w >= wst[nw] moved
+            // cur_w to nw, read wst[nw + 1] - one int past the array - and spun the full 20000 x s_sleep on a gate that stops at
+            // nw - 1: ~1.7 ms at the end of EVERY launch, 20 launches per epoch.  ADVICE r04.)
+            if (!paced || i >= rounds || cur_w >= pace.nw - 1) return;
             const int st_w = __builtin_amdgcn_readfirstlane(gid + NGB * i);   // the wave's first group decides for both
             if (st_w < next_b) return;
             do {

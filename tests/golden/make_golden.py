@@ -154,7 +154,46 @@ def c3r_wmrb():
          recall10_mean=float(D.recall_at_k_dense(out['U'], out['V'], A, 10).mean()))
 
 
+def plugin_inputs(seed=7, m=40, n=30, r=6):
+    """Small mixed-sign problem with dense NON-identity features for the plug-ins beyond Linear + MSE / WMRB:
+    BiasedLinearEmbedding / ReLUEmbedding (embedding_graphs.py:41-87) and KLDivergenceLoss (loss_graphs.py:91-122)."""
+    rng = np.random.default_rng(seed)
+    A = ((rng.random((m, n)) < 0.3) * rng.integers(-2, 6, (m, n))).astype(np.float32)
+    idx, val = np.argwhere(A != 0).astype(np.int64), A[A != 0]
+    return dict(A=A, indices=idx, values=val,
+                U0=(rng.standard_normal((m, r)) * 0.3).astype(np.float32), V0=(rng.standard_normal((n, r)) * 0.3).astype(np.float32),
+                Fu=(np.eye(m) + 0.05 * rng.random((m, m))).astype(np.float32), Fv=(np.eye(n) + 0.05 * rng.random((n, n))).astype(np.float32),
+                U0_relu=(rng.standard_normal((5 * r, r)) * 0.3).astype(np.float32),        # ReLUEmbedding: weights are [aux_dim = 5 r, r]
+                relu_w0=(rng.standard_normal((m, 5 * r)) * 0.2).astype(np.float32))        # the matrix TF would draw at first use
+
+
+PLUGIN_CASES = {'plugin_biased': dict(loss='mse', user_embedding='biased', item_embedding='biased'),
+                'plugin_relu': dict(loss='mse', user_embedding='relu'),
+                'plugin_kl': dict(loss='kl')}
+PLUGIN_EPOCHS, PLUGIN_LR = 12, 0.02
+
+
+def plugin_case(name):
+    p = plugin_inputs()
+    kw = dict(PLUGIN_CASES[name])
+    relu = kw.get('user_embedding') == 'relu'
+    out = D.fit_dense_plugins(p['U0_relu'] if relu else p['U0'], p['V0'], p['indices'], p['values'], kw.pop('loss'), PLUGIN_EPOCHS,
+                              PLUGIN_LR, p['Fu'], p['Fv'], user_relu_weight0=p['relu_w0'] if relu else None, record_epochs=(1,), **kw)
+    fx = dict(p, lr=PLUGIN_LR, epochs=PLUGIN_EPOCHS, loss=out['loss'], user_embedding=out['user_embedding'],
+              item_embedding=out['item_embedding'])
+    for side, (first, last) in dict(user=(out['snapshots'][1][0], out['user_vars']), item=(out['snapshots'][1][1], out['item_vars'])).items():
+        for i, (a, b) in enumerate(zip(first, last)):
+            fx[f'{side}_var{i}_1'], fx[f'{side}_var{i}_{PLUGIN_EPOCHS}'] = a, b
+    return fx
+
+
+def plugins():
+    for name in PLUGIN_CASES:
+        save(name, **plugin_case(name))
+
+
 if __name__ == '__main__':
+    plugins()
     gather_known_answer()
     c1_mse()
     wmrb_small()

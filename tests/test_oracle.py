@@ -277,3 +277,82 @@ def test_closed_form_gradients_match_finite_differences(loss):
             W[i, c] = keep
             fd = (up - dn) / (2 * h)
             assert abs(fd - g[i, c]) <= 1e-6 * max(1.0, np.abs(g).max()), (name, i, c, fd, g[i, c])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the plug-ins beyond Linear + MSE / WMRB: oracle.dense_ref.fit_dense_plugins
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', sorted(MG.PLUGIN_CASES))
+def test_plugin_fixtures_are_current_oracle_output(golden, name):
+    g, now = golden(name), MG.plugin_case(name)
+    assert set(g) == set(now)
+    for k in g:
+        assert np.array_equal(g[k], np.asarray(now[k])), k
+    assert np.isfinite(g['loss']).all() and g['loss'][-1] < g['loss'][0]
+
+
+def test_tfp_normal_cdf_restatement_against_scipy():
+    from scipy.special import ndtr
+    z = np.concatenate([np.linspace(-9, 9, 181), [-0.70710678, 0.70710678, 0.0]])
+    assert np.abs(D.tfp_ndtr(torch.tensor(z)).numpy() - ndtr(z)).max() < 1e-15
+    assert rel_err(D.tfp_ndtr(torch.tensor(z, dtype=torch.float32)).numpy(), ndtr(z)) < 1e-6
+
+
+def _plugin_loss_by_definition(case, Fu, Fv, idx, val, uv, iv):
+    """Sum of the loss of one epoch written out from the definitions (embedding_graphs.py:38 / :58 / :85-87, loss_graphs.py:52 /
+    :109-122) in plain NumPy with SciPy's normal CDF - neither torch nor any helper of the oracle."""
+    from scipy.special import ndtr
+
+    def emb(kind, F, vs):
+        if kind == 'linear':
+            return F @ vs[0]
+        if kind == 'biased':
+            return F @ vs[0] + vs[1]
+        return np.maximum(F @ vs[1] + vs[2], 0.0) @ vs[0]
+    P = emb(case.get('user_embedding', 'linear'), Fu, uv) @ emb(case.get('item_embedding', 'linear'), Fv, iv).T
+    p = P[idx[:, 0], idx[:, 1]]
+    if case['loss'] == 'mse':
+        return float(((val - p) ** 2).sum())
+    pos, neg = p[val > 0], p[val <= 0]
+    loc = neg.mean() - pos.mean()
+    scale = np.sqrt(((pos - pos.mean()) ** 2).mean() + ((neg - neg.mean()) ** 2).mean())
+    return float(1.0 - ndtr((0.0 - loc) / scale))
+
+
+@pytest.mark.parametrize('name', sorted(MG.PLUGIN_CASES))
+def test_plugin_oracle_step_matches_finite_differences(name):
+    """The plug-in oracle differentiates by autograd; this line of evidence does not: central differences (fp64) of the epoch's
+    loss written out from its definition give the gradient of EVERY trainable, and the oracle's first fresh-Adam step (fp64 run)
+    must lie in the step interval of that gradient."""
+    case = dict(MG.PLUGIN_CASES[name])
+    rng = np.random.default_rng(11)
+    m, n, r = 9, 7, 2
+    A = ((rng.random((m, n)) < 0.5) * rng.integers(-2, 6, (m, n))).astype(np.float64)
+    idx, val = np.argwhere(A != 0), A[A != 0]
+    Fu, Fv = np.eye(m) + 0.1 * rng.random((m, m)), np.eye(n) + 0.1 * rng.random((n, n))
+    relu = case.get('user_embedding') == 'relu'
+    U0 = rng.standard_normal((5 * r if relu else m, r)) * 0.4
+    V0 = rng.standard_normal((n, r)) * 0.4
+    relu_w0 = rng.standard_normal((m, 5 * r)) * 0.3 if relu else None
+    lr = 0.05
+    out = D.fit_dense_plugins(U0, V0, idx, val, case['loss'], 1, lr, Fu, Fv, user_embedding=case.get('user_embedding', 'linear'),
+                              item_embedding=case.get('item_embedding', 'linear'), user_relu_weight0=relu_w0, dtype=torch.float64)
+    uv = [U0] + ([np.zeros((1, r))] if case.get('user_embedding') == 'biased' else []) + ([relu_w0, np.zeros((1, 5 * r))] if relu else [])
+    iv = [V0] + ([np.zeros((1, r))] if case.get('item_embedding') == 'biased' else [])
+    assert rel_err(out['loss'][0] * (len(val) if case['loss'] == 'mse' else 1), _plugin_loss_by_definition(case, Fu, Fv, idx, val, uv, iv)) < 1e-12
+    if relu:   # away from the kink of the ReLU, so that the loss is smooth where it is differenced
+        assert np.abs(Fu @ relu_w0).min() > 1e-4
+    h = 1e-6
+    for vs, new in ((uv, out['user_vars']), (iv, out['item_vars'])):
+        for W, W1 in zip(vs, new):
+            g = np.zeros_like(W)
+            for pos in np.ndindex(*W.shape):
+                keep = W[pos]
+                W[pos] = keep + h
+                up = _plugin_loss_by_definition(case, Fu, Fv, idx, val, uv, iv)
+                W[pos] = keep - h
+                dn = _plugin_loss_by_definition(case, Fu, Fv, idx, val, uv, iv)
+                W[pos] = keep
+                g[pos] = (up - dn) / (2 * h)
+            assert np.abs(g).max() > 0
+            assert_step(W1, W, g, lr, rtol=1e-5, what=name)
