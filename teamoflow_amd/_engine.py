@@ -457,6 +457,9 @@ def scores5_wanted(plan, wplan, n_components, dtype=torch.float32):
     (profiles/r04_scores5_experiment.txt).  Needs rows of 32 lanes, fewer than 2^24 items and a table below 4 GB."""
     if os.environ.get('TMF_SCORES5') != '1' or wplan is None or not wplan.sliced or not plan.col_u.is_cuda:
         return False
+    m, S = wplan.R.shape
+    if m * S >= 2 ** 31 or plan.nnz >= 2 ** 31:   # the stream's int32 places (sp index / ~p index): such shapes stay with scores3
+        return False
     return bool(_lib.load_library().tmf_wmrb_scores5_supported(int(n_components), int(dtype is torch.bfloat16), int(plan.n_items)))
 
 
@@ -472,6 +475,7 @@ class Scores5Plan:
     def __init__(self, plan, wplan, n_components, dtype=torch.float32, slice_bytes=None):
         lib = _lib.get()
         dev = plan.col_u.device
+        self.key = (int(n_components), dtype)   # what the streams were built for (the slice width follows the row bytes)
         UB = int(lib.tmf_wmrb_scores5_users_per_workgroup())
         m, S = wplan.R.shape
         nnz, n = plan.nnz, plan.n_items
@@ -526,7 +530,8 @@ class Scores5Plan:
         # Window 0 is empty: passing it is the start line (every workgroup has its rows in LDS).  wstart = first step (8 entries)
         # of every window in every workgroup's stream; the padding sits behind a workgroup's last entry, so offsets inside a
         # workgroup are those of the sorted list
-        every = max(1, int(os.environ.get('TMF_S5_PACE_EVERY', 32)))
+        # at most kS5MaxWindows (4096) windows: their first steps sit in LDS - a smaller request is widened, never an error
+        every = max(1, int(os.environ.get('TMF_S5_PACE_EVERY', 32)), -(-ns // 4000))
         firsts = list(range(0, ns, every))
         off = rowptr[:n_wg * ns].view(n_wg, ns)[:, firsts] - wg_ptr[:-1, None]
         self.n_windows = nwin = len(firsts) + 1
@@ -584,8 +589,11 @@ class TrainState:
             else:
                 self.part_layers, self.gradu_launches = 1, 1           # a launch per slice
             need.update(sp=m * S, pk=max(plan.nnz, 1), part=self.part_layers * max(m, 1) * self.ld)
-            if getattr(wplan, 's5', None) is None and wplan.seg_e is not None and scores5_wanted(plan, wplan, self.r, dtype):
-                wplan.s5 = Scores5Plan(plan, wplan, self.r, dtype)
+            if wplan.seg_e is not None and scores5_wanted(plan, wplan, self.r, dtype):
+                if getattr(wplan, 's5', None) is None or wplan.s5.key != (self.r, dtype):
+                    wplan.s5 = Scores5Plan(plan, wplan, self.r, dtype)
+            else:
+                wplan.s5 = None
         if wplan is not None and wplan.rows4:
             L = _lib.load_library()
             per_group = L.tmf_wsum_rows4_rows_per_group(self.r, int(dtype is torch.bfloat16))

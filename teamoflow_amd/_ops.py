@@ -70,6 +70,7 @@ def fused_topk_supported(user_embedding, item_embedding, k):
     return k <= FUSED_MAX_K and user_embedding.shape[1] <= (FUSED_MAX_R_BF16 if bf16 else FUSED_MAX_R)
 
 
+BF16_UPCAST_WINDOWS = 8       # item windows of the same path when the fp32 copy of the whole item table does not fit
 BF16_UPCAST_USERS = 1 << 18   # users per call when bf16 tables are ranked through the fp32 kernel (bounds the fp32 copy of their rows)
 
 
@@ -96,6 +97,11 @@ def half2_range_ok(item_rows):
     low = torch.where(row_max > 0, row_max, top).min()
     top, low = float(top), float(low)
     return top == 0.0 or (top < float('inf') and low > 0 and top / low <= HALF2_MAX_ROW_RANGE)
+
+
+def _upcast_table(B):
+    """Exact fp32 copy of a bf16 item table (twice its size; torch.OutOfMemoryError when it does not fit)."""
+    return B.float()
 
 
 def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, return_values=False, arithmetic=None):
@@ -127,14 +133,35 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
         if FUSED_MAX_K_BF16 < k <= FUSED_MAX_K:
             # The bf16 kernel keeps 256 users' lists in LDS: k <= 32.  Beyond it the fp32 fused kernel (k <= 64) ranks exact fp32
             # copies of the rows - a bf16 x bf16 product is exact in fp32 either way, the fp32 sums differ in order only.
-            Bf = B.float()
+            # Costs a transient fp32 copy of the item table (twice its size); when that does not fit the catalog is ranked in windows
+            # of rows (a copy of one window at a time) and the per-window lists are merged by one stable top-k - windows in catalog
+            # order, so equal scores keep ascending item order.
+            if m == 0:
+                idx = torch.empty(0, k, dtype=torch.int32, device=A.device)
+                return (torch.empty(0, k, dtype=torch.float32, device=A.device), idx) if return_values else idx
+            try:
+                windows = [(0, _upcast_table(B))]
+            except torch.OutOfMemoryError:
+                step = max(k, -(-n // BF16_UPCAST_WINDOWS))
+                windows = [(c0, None) for c0 in range(0, n, step)]
+                if n - windows[-1][0] < k:   # a last window narrower than k joins the one before it
+                    windows.pop()
             out_i, out_v = [], []
             for b in range(0, m, BF16_UPCAST_USERS):
-                r_ = predict_topk(A[b:b + BF16_UPCAST_USERS].float(), Bf, k, clamp_negatives=clamp_negatives, return_values=return_values,
-                                  arithmetic='fp32')
-                out_i.append(r_[1] if return_values else r_)
-                if return_values:
-                    out_v.append(r_[0])
+                Au = A[b:b + BF16_UPCAST_USERS].float()
+                cand_v, cand_i = [], []
+                for w, (c0, Bf) in enumerate(windows):
+                    c1 = windows[w + 1][0] if w + 1 < len(windows) else n
+                    v_, i_ = predict_topk(Au, Bf if Bf is not None else B[c0:c1].float(), k, clamp_negatives=clamp_negatives,
+                                          return_values=True, arithmetic='fp32')
+                    cand_v.append(v_)
+                    cand_i.append(i_ + c0)
+                if len(windows) > 1:
+                    cv, ci = torch.cat(cand_v, dim=1), torch.cat(cand_i, dim=1)
+                    v_, pos = topk_stable(cv, k, return_values=True)
+                    cand_v, cand_i = [v_], [torch.gather(ci, 1, pos.long())]
+                out_v.append(cand_v[0])
+                out_i.append(cand_i[0])
             idx = torch.cat(out_i) if len(out_i) > 1 else out_i[0]
             return ((torch.cat(out_v) if len(out_v) > 1 else out_v[0]), idx) if return_values else idx
         idx = torch.empty(m, k, dtype=torch.int32, device=A.device)

@@ -61,7 +61,9 @@ __device__ __forceinline__ void search_step(const float* __restrict__ ts, const 
 
 // `nfin` = finite thresholds of the chunk (they sort to the front; everything behind them is +inf).  A step whose probe position
 // lies at or beyond nfin reads +inf and never moves: the search starts at the first step that can (a chunk of <= 63 thresholds - most
-// users - takes 6 steps instead of 8, <= 31 five).  Wave-uniform choice; the result is the same by construction.
+// users - takes 6 steps instead of 8, <= 31 five).  Wave-uniform choice.  A sample of +inf (an overflowed score) also passes the
+// +inf padding, so its position depends on the steps taken: rho is clamped to nfin, i.e. such a sample is active for EVERY positive -
+// what the reference computes (1 - p + inf = inf: M = inf, loss = inf, w = c / (1 + inf) = 0, so delta and D are 0).
 __device__ __forceinline__ void search_tile(const float* __restrict__ ts, const float (&x)[HSPL], int (&rho)[HSPL], int nfin) {
     int pp[HSPL];
 #pragma unroll
@@ -75,7 +77,10 @@ __device__ __forceinline__ void search_tile(const float* __restrict__ ts, const 
     search_step<2>(ts, x, pp);
     search_step<1>(ts, x, pp);
 #pragma unroll
-    for (int j = 0; j < HSPL; ++j) rho[j] = pp[j] - pp[j] / 33;  // padded -> plain position
+    for (int j = 0; j < HSPL; ++j) {
+        const int r = pp[j] - pp[j] / 33;  // padded -> plain position
+        rho[j] = r < nfin ? r : nfin;
+    }
 }
 
 __device__ __forceinline__ void load_tile(const float* __restrict__ spu, int s0, int S, int lane, float (&x)[HSPL]) {

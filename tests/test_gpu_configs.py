@@ -237,6 +237,40 @@ def test_hinge_kernel_alone(tm, case):  # noqa: F811
         assert all(np.array_equal(a, b) for a, b in zip(first, again))
 
 
+@pytest.mark.parametrize('npos', [7, 15, 31, 63, 100, 255])
+def test_hinge_kernel_with_an_infinite_score(tm, npos):  # noqa: F811
+    """the binary search skips the steps a short chunk cannot need, so a sample of +inf (an overflowed score) no longer
+    ran to slot 255 but stopped at 15 / 31 / 63 - and was counted or dropped depending on whether that happened to equal the
+    number of positives.  It is active for EVERY positive now, as in the reference (loss_graphs.py:80-88: 1 - p + inf = inf, M = inf,
+    loss = inf, w = c / (1 + inf) = 0): the user's loss is +inf, its delta and D are 0; the other users are untouched."""
+    import ctypes
+    rng = np.random.default_rng(npos)
+    lib = tm.lib.get()
+    S_, degs = 200, [npos, 9, npos]
+    m = len(degs)
+    rowptr = np.concatenate([[0], np.cumsum(degs)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    val = np.ones(nnz, np.float32)
+    p = rng.standard_normal(nnz).astype(np.float32)
+    sp = rng.standard_normal((m, S_)).astype(np.float32)
+    sp[0, 17] = np.inf
+    sp[2, 3] = -np.inf          # never active: contributes nothing, like any very negative score
+    c = 12.5
+    t = lambda a, dt: torch.tensor(a, dtype=dt, device='cuda')  # noqa: E731
+    d_rowptr, d_val, d_p, d_sp = t(rowptr, torch.int64), t(val, torch.float32), t(p, torch.float32), t(sp, torch.float32)
+    delta, D, loss = torch.full((nnz,), 7.0, device='cuda'), torch.full((m, S_), 7.0, device='cuda'), torch.full((m,), 7.0, device='cuda')
+    tm.lib.check(lib.tmf_wmrb_hinge2(tm.lib.ptr(d_rowptr), tm.lib.ptr(d_val), tm.lib.ptr(d_p), tm.lib.ptr(d_sp), ctypes.c_int32(m),
+                                     ctypes.c_int32(S_), c, tm.lib.ptr(delta), tm.lib.ptr(D), tm.lib.ptr(loss), tm.lib.stream_ptr()), lib)
+    torch.cuda.synchronize()
+    delta, D, loss = delta.cpu().numpy(), D.cpu().numpy(), loss.cpu().numpy()
+    with np.errstate(invalid='ignore', over='ignore'):
+        r_delta, r_D, r_loss = hinge_reference(rowptr, val, p, sp, c)
+    assert np.isposinf(r_loss[0]) and (r_delta[:npos] == 0).all() and (r_D[0] == 0).all()      # what the formula gives
+    assert np.isposinf(loss[0]) and (delta[:npos] == 0).all() and (D[0] == 0).all()
+    assert rel_err(delta[npos:], r_delta[npos:]) < 1e-5 and rel_err(D[1:], r_D[1:]) < 1e-5
+    assert np.abs(loss[1:] - r_loss[1:]).max() <= 1e-5 * np.abs(r_loss[1:]).max()
+
+
 def test_slice_grids_beyond_one_launch(tm, monkeypatch):  # noqa: F811
     """A HIP launch carries < 2^32 work-items.  1.1M users x 512 slices is 34375 user groups x 512 slices x 256 threads =
     4.5e9 for the slice-major kernels: they have to go out in several launches of whole slices (found in round 3, when such a

@@ -874,3 +874,32 @@ def test_randomized_fused_topk(tm, seed):
         gb = tm.ops.predict_topk(torch.tensor(U).to(torch.bfloat16).cuda(), torch.tensor(V).to(torch.bfloat16).cuda(), k,
                                  clamp_negatives=clamp).cpu().numpy()
         assert np.array_equal(gb, ref), (m, n, r, k, clamp, 'bf16')
+
+
+def test_bf16_tables_beyond_k32_windowed_when_the_fp32_copy_does_not_fit(tm, monkeypatch):
+    """32 < k <= 64 on bf16 tables ranks exact fp32 copies of the rows - with no users that raised IndexError, and
+    the fp32 copy of the whole item table had no out-of-memory path.  Now: empty in -> empty out; when the copy does not fit the
+    catalog is ranked in windows and the lists merged - same ids, ties in catalog order included."""
+    from oracle import sparse_ref as S
+    rng = np.random.default_rng(99)
+    m, n, r, k = 70, 1900, 40, 48
+    U = rng.integers(-2, 3, (m, r)).astype(np.float32)
+    V = rng.integers(-2, 3, (n, r)).astype(np.float32)           # small integers: many exact ties, also across windows
+    Ub, Vb = torch.tensor(U).to(torch.bfloat16).cuda(), torch.tensor(V).to(torch.bfloat16).cuda()
+    for clamp in (False, True):
+        sc = U @ V.T
+        ref = S.topk_stable(np.where(sc > 0, sc, 0) if clamp else sc, k)
+        whole = tm.ops.predict_topk(Ub, Vb, k, clamp_negatives=clamp)
+
+        def no_room(B):
+            raise torch.OutOfMemoryError('forced by the test')
+        with monkeypatch.context() as mp:
+            mp.setattr(tm.ops, '_upcast_table', no_room)
+            vals, windowed = tm.ops.predict_topk(Ub, Vb, k, clamp_negatives=clamp, return_values=True)
+        assert np.array_equal(whole.cpu().numpy(), ref) and np.array_equal(windowed.cpu().numpy(), ref), clamp
+        want = np.take_along_axis(np.where(sc > 0, sc, 0) if clamp else sc, ref, axis=1)
+        assert np.array_equal(vals.cpu().numpy(), want)
+    empty = tm.ops.predict_topk(Ub[:0], Vb, k)
+    assert tuple(empty.shape) == (0, k) and empty.dtype == torch.int32
+    v0, i0 = tm.ops.predict_topk(Ub[:0], Vb, k, return_values=True)
+    assert tuple(v0.shape) == (0, k) and tuple(i0.shape) == (0, k)
