@@ -199,6 +199,14 @@ def mse_kernel_models(m, n, nnz, ld, s):
     return k
 
 
+def survey_algorithmic_bytes(loss, m, n, S, nnz, P, r, s):
+    """SURVEY.md §8d's ALGORITHMIC bytes of one epoch (every gathered row counted, wherever it is served from):
+    MSE  nnz (2 r s + 24) + (m + n) 2 r s;   WMRB  m S 3 r s + m S 16 + P (2 r s + 24) + (m + n) 2 r s."""
+    if loss == 'mse':
+        return float(nnz) * (2 * r * s + 24) + float(m + n) * 2 * r * s
+    return float(m) * S * 3 * r * s + float(m) * S * 16 + float(P) * (2 * r * s + 24) + float(m + n) * 2 * r * s
+
+
 def epoch_hbm_frac(models, seconds):
     """Compulsory HBM bytes of the epoch over its time against the HBM peak; None when the no-reuse model of a gather from a
     table beyond the Infinity Cache over-counts (skewed row popularity) and the figure would exceed 1."""
@@ -476,11 +484,11 @@ def small_configs(dev, quick=False):
 
 LINE_HARD_CAP = 8192   # bytes: the driver keeps only a tail of stdout, so the ONE line must stay small (round 3's 20.5 KB line was cut)
 LINE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
-             'data', 'config', 'roofline', 'cpu_baseline', 'predict_rows_per_sec', 'predict_tflops', 'predict_arithmetic',
+             'data', 'config', 'roofline', 'cpu_baseline', 'hbm_legs', 'predict_rows_per_sec', 'predict_tflops', 'predict_arithmetic',
              'predict_top10_rows_identical_to_fp64', 'recall_at_10',
              'hinge_terms_per_sec', 'collectives', 'extras')
 ROOFLINE_KEYS = ('bound', 'kernel', 'kernel_ms', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'hbm_traffic_frac', 'traffic_over_compulsory',
-                 'useful_hbm_frac', 'l2_hit_rate', 'traffic_source', 'csrc_sha', 'epoch_hbm_frac', 'kernels_ms')
+                 'useful_hbm_frac', 'l2_hit_rate', 'traffic_source', 'csrc_sha', 'epoch_hbm_frac', 'algorithmic_over_hbm_peak', 'kernels_ms')
 
 
 def _short(x, digits=6):
@@ -512,6 +520,15 @@ def compact_line(out):
         c = out['cpu_baseline']
         line['cpu_baseline'] = {k: c[k] for k in ('value', 'unit', 'cores', 'kind') if k in c}
         line['cpu_baseline']['sample'] = str(c.get('sample', ''))[:240]
+    if 'hbm_legs' in out:
+        # the two side legs whose factor rows really come from HBM, in short: epoch time, interactions per second, and
+        # per kernel [ms, roof, fraction of that roof] - driver-parsed numbers instead of extras-file ones
+        line['hbm_legs'] = {name: dict(ms_per_step=leg.get('ms_per_step'), value=leg.get('value'), unit=leg.get('unit'), dtype=leg.get('dtype'),
+                                       epoch_hbm_frac=leg.get('epoch_hbm_frac'),
+                                       kernels_ms={e['kernel']: [round(e['ms'], 3), e['bound'].split(' ')[0],
+                                                                 round(e['frac'], 3) if e.get('frac') is not None else None]
+                                                   for e in leg.get('kernels', [])})
+                            for name, leg in out['hbm_legs'].items()}
     if 'recall_at_10' in out:
         q = out['recall_at_10']
         line['recall_at_10'] = {k: q[k] for k in ('engine', 'oracle', 'abs_diff') if k in q}
@@ -523,7 +540,7 @@ def compact_line(out):
     line = _short(line)
     text = json.dumps(line, separators=(',', ':'))
     if len(text) > LINE_HARD_CAP:   # never print a line the driver cannot take: drop the optional parts, largest first
-        for k in ('collectives', 'hinge_terms_per_sec', 'extras'):
+        for k in ('collectives', 'hinge_terms_per_sec', 'extras', 'hbm_legs'):
             line.pop(k, None)
         line['roofline'].pop('kernels_ms', None)
         line['cpu_baseline'] = {k: v for k, v in line.get('cpu_baseline', {}).items() if k != 'sample'}
@@ -1016,6 +1033,12 @@ def main():
                     kernel_ms=top['ms'], kernels=kernels, csrc_sha=csrc_sha(),
                     epoch_hbm_bytes=sum(k['hbm'] for k in models.values()),
                     epoch_hbm_frac=epoch_hbm_frac(models, ms_per_step * 1e-3),
+                    # SURVEY §8d's figure next to the L2 one, so that nobody reads `frac` as an HBM fraction: the epoch's algorithmic bytes
+                    # (every gathered row counted) over its time against the 8 TB/s HBM peak - above 1 at C4 because the path is blocked
+                    # so that the gathered rows are served by the L2s, not by HBM
+                    epoch_algorithmic_bytes=survey_algorithmic_bytes(args.loss, wl.m, wl.n, wl.S, wl.nnz, wl.plan.n_pos, wl.r, 2 if args.dtype == 'bf16' else 4),
+                    algorithmic_over_hbm_peak=survey_algorithmic_bytes(args.loss, wl.m, wl.n, wl.S, wl.nnz, wl.plan.n_pos, wl.r,
+                                                                       2 if args.dtype == 'bf16' else 4) / (ms_per_step * 1e-3) / HBM_PEAK,
                     epoch_gather_bytes=sum(k['gather'] for k in models.values()),
                     epoch_gather_rate_GBps=sum(k['gather'] for k in models.values()) / (ms_per_step * 1e-3) / 1e9,
                     l2_gather_rate_measured_by_guide_GBps=[x / 1e9 for x in L2_GATHER_MEASURED],

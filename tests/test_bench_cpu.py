@@ -40,7 +40,7 @@ def stub_out(bench):
                     traffic=top.get('traffic'), hbm_traffic_frac=top.get('hbm_traffic_frac'), traffic_source='profiles/pmc_c4_latest.json',
                     traffic_over_compulsory=top.get('traffic_over_compulsory'), useful_hbm_frac=top.get('useful_hbm_frac'),
                     l2_hit_rate=top.get('l2_hit_rate'), kernel_ms=top['ms'], kernels=kernels, csrc_sha='0123456789abcdef',
-                    epoch_hbm_bytes=7.3e10, epoch_hbm_frac=0.1, epoch_gather_bytes=1.7e12, note='x' * 700)
+                    epoch_hbm_bytes=7.3e10, epoch_hbm_frac=0.1, algorithmic_over_hbm_peak=2.42, epoch_gather_bytes=1.7e12, note='x' * 700)
     filler = {f'key{i}': dict(a=1.23456789012345, b='y' * 300, c=list(range(40))) for i in range(40)}
     return dict(metric='train_interactions_per_sec', value=1.1123456789e9, unit='interactions/s', n_gpus=1, steps=20, warmup=5,
                 ms_per_step=89.123456, higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
@@ -54,7 +54,9 @@ def stub_out(bench):
                 predict_top10_rows_identical_to_fp64=1.0, predict_by_arithmetic=filler,
                 recall_at_10=dict(engine=0.5, oracle=0.5, abs_diff=6e-8, case='C1', end_to_end_C2=dict(engine=0.1, oracle=0.1, abs_diff=5e-10, case='C2')),
                 api_fit=filler, item_sharded_fit=filler, reference_formulation_cpu=filler, strong_scaling_projection=filler,
-                hbm_legs=dict(c4_mse=dict(kernels=kernels, **filler), c5_shard_bf16=dict(kernels=kernels, **filler)))
+                hbm_legs=dict(c4_mse=dict(kernels=kernels, ms_per_step=10.79, value=9.25e9, unit='interactions/s', dtype='f32', epoch_hbm_frac=0.6, **filler),
+                              c5_shard_bf16=dict(kernels=kernels, ms_per_step=237.4, value=5.26e8, unit='interactions/s',
+                                                 dtype='bf16 storage / f32 arithmetic', epoch_hbm_frac=None, **filler)))
 
 
 def test_the_bench_line_is_compact_and_complete(bench, tmp_path):
@@ -68,11 +70,14 @@ def test_the_bench_line_is_compact_and_complete(bench, tmp_path):
     contract = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
                 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
     assert contract <= set(line), contract - set(line)
-    assert {'predict_rows_per_sec', 'predict_tflops', 'predict_arithmetic', 'recall_at_10', 'extras'} <= set(line)
+    assert {'predict_rows_per_sec', 'predict_tflops', 'predict_arithmetic', 'recall_at_10', 'extras', 'hbm_legs'} <= set(line)
+    # the HBM-streaming side legs are driver-parsed numbers now: epoch time, rate, per kernel [ms, roof, fraction]
+    assert line['hbm_legs']['c4_mse']['value'] == 9.25e9 and len(line['hbm_legs']['c5_shard_bf16']['kernels_ms']) == 6
+    assert set(line['hbm_legs']['c4_mse']) == {'ms_per_step', 'value', 'unit', 'dtype', 'epoch_hbm_frac', 'kernels_ms'}
     assert set(line) <= set(bench.LINE_KEYS)
     assert {'workload', 'interactions_total', 'parallelism'} <= set(line['config'])
     assert {'bound', 'kernel', 'kernel_ms', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'hbm_traffic_frac', 'traffic_source', 'csrc_sha',
-            'epoch_hbm_frac', 'traffic_over_compulsory', 'useful_hbm_frac'} <= set(line['roofline'])
+            'epoch_hbm_frac', 'traffic_over_compulsory', 'useful_hbm_frac', 'algorithmic_over_hbm_peak'} <= set(line['roofline'])
     assert {'value', 'unit', 'cores', 'kind', 'sample'} == set(line['cpu_baseline'])
     assert line['roofline']['kernel'] == 'wmrb_item_pass' and len(line['roofline']['kernels_ms']) == 6
     assert abs(line['value'] - out['value']) < 1e-5 * out['value'] and line['recall_at_10']['abs_diff'] == 6e-8

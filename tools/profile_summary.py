@@ -86,6 +86,47 @@ out['_csrc_sha'] = bench.csrc_sha()   # bench.py quotes these counters only for 
 out['_note'] = ('traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024: on gfx950 FETCH_SIZE counts half of the bytes of 16 B/lane '
                 'coalesced reads (MI355X_MICROARCH.md, HBM section); FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes')
 json.dump(out, open(os.path.join(dst, f'{tag}_pmc.json'), 'w'), indent=1)
+
+# The roofline from THIS directory alone: per kernel the rocprofv3 average duration of the traced run, the bytes
+# of bench.py's byte model for the same run (gather = every gathered row counted; compulsory = what must cross HBM at least
+# once) and both fractions priced on the trace's own durations - next to the HIP-event milliseconds the bench line quotes.
+roof = {}
+try:
+    ex = json.load(open(os.path.join(src, 'bench_trace_extras.json')))
+    stats = {}
+    for r in rows:
+        nm = demangle(r['Name']) if r['Name'].startswith('_ZN3tmf') else r['Name']
+        stats[nm.split('(')[0].replace('void ', '')] = r
+    entries = list(ex.get('roofline', {}).get('kernels', []))
+    for e in entries:
+        pat = bench.PMC_KERNELS.get(e['kernel'])
+        prefix = pat[0] if isinstance(pat, tuple) else pat
+        hit = [(k, v) for k, v in stats.items() if prefix and k.startswith(prefix)]
+        if not hit:
+            continue
+        calls = sum(int(v['Calls']) for _, v in hit)
+        total_ns = sum(float(v['TotalDurationNs']) for _, v in hit)
+        per_epoch = max(1, round(calls / max(ex.get('steps', 1) + ex.get('warmup', 0), 1)))      # launches of the kernel per epoch
+        ns = total_ns / calls * per_epoch                                                          # per epoch, like the event brackets
+        d = dict(rocprof_symbol=hit[0][0][:80], rocprof_calls=calls, launches_per_epoch=per_epoch, rocprof_avg_ns_per_epoch=ns,
+                 hip_event_ms=e['ms'], rocprof_over_event=ns * 1e-6 / e['ms'], compulsory_hbm_bytes=e['hbm_bytes'],
+                 useful_hbm_frac_rocprof=e['hbm_bytes'] / (ns * 1e-9) / bench.HBM_PEAK)
+        if e.get('gather_bytes'):
+            d.update(gather_bytes=e['gather_bytes'], l2_frac_rocprof=e['gather_bytes'] / (ns * 1e-9) / bench.L2_PEAK,
+                     l2_frac_events=e.get('l2_frac'))
+        roof[e['kernel']] = d
+    roof['_epoch'] = dict(ms_per_step=ex.get('ms_per_step'), algorithmic_bytes=ex.get('roofline', {}).get('epoch_algorithmic_bytes'),
+                          algorithmic_over_hbm_peak=ex.get('roofline', {}).get('algorithmic_over_hbm_peak'),
+                          epoch_hbm_frac=ex.get('roofline', {}).get('epoch_hbm_frac'), csrc_sha=out['_csrc_sha'],
+                          note='rocprof durations are of the TRACED run (kernel-trace adds a few per cent on this pool); the bench line quotes '
+                               'HIP-event brackets of an untraced run; rocprof_over_event says how far apart the two are')
+    json.dump(roof, open(os.path.join(dst, f'{tag}_roofline.json'), 'w'), indent=1)
+except (OSError, ValueError, KeyError) as err:
+    print(f'no roofline file: {err!r}')
 print(open(os.path.join(dst, f'{tag}_kernel_stats.csv')).read()[:1500])
+if roof:
+    print(json.dumps({k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a in
+                          ('rocprof_avg_ns_per_epoch', 'hip_event_ms', 'rocprof_over_event', 'l2_frac_rocprof', 'useful_hbm_frac_rocprof')}
+                      for k, v in roof.items() if not k.startswith('_')}, indent=1))
 print(json.dumps({k: dict(traffic_GB=round(v.get('hbm_traffic_bytes_per_launch_corrected', 0) / 1e9, 2), l2_hit_rate=v.get('l2_hit_rate'))
                   for k, v in out.items() if not k.startswith('_')}, indent=1))
