@@ -150,7 +150,7 @@ def init_table(rows, r, seed, dev):
 #             (or the cache-sized window the kernel is blocked into) once per sweep when it is cache-resident
 #             (<= 256 MiB Infinity Cache), every gathered row when it is not.
 # ---------------------------------------------------------------------------------------------
-def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, part_layers=None):
+def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, part_layers=None, u_sweeps=1):
     row = ld * s          # bytes of one factor row as stored
     row32 = ld * 4        # fp32 partial / gradient rows
     U_tab, V_tab = m * row, n * row
@@ -177,10 +177,14 @@ def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, p
                                    hbm=m * S * 4 + 2 * nnz * 4 + 2 * U_tab + (V_tab if V_tab <= MALL_BYTES else 2 * (m * S + nnz) * row) + m * S * 4 + nnz * 4,
                                    roof='l2' if V_tab <= MALL_BYTES else 'hbm', what='fused user pass (one workgroup per user)')
     u_resident = U_tab <= MALL_BYTES or C > 1   # user-blocked lists: the block being gathered from is L2-resident
+    # u_sweeps > 1: the row-stationary form (tmf_wsum_rows5) - every launch of resident lane groups walks ALL user blocks, so U
+    # crosses HBM once per launch; its slab holds only the parts of the rows it cut (popular items), the rest is finished in place
     k['wmrb_item_pass'] = dict(rows=E_lists, gather=E_lists * row,
-                               hbm=E_lists * 12 + (U_tab if u_resident else E_lists * row) + (n_slab * row32 if n_slab else 2 * V_tab),
+                               hbm=E_lists * 12 + (u_sweeps * U_tab if u_resident else E_lists * row)
+                               + (n_slab * row32 + (2 * V_tab if u_sweeps > 1 else 0) if n_slab else 2 * V_tab),
                                roof='l2' if u_resident else 'hbm',
-                               what='weighted U-row gather-sum over the (user block, item) lists; 4-byte weight gathers')
+                               what=('row-stationary weighted U-row gather-sum: lane groups own (virtual) item rows and walk the user blocks; '
+                                     if u_sweeps > 1 else 'weighted U-row gather-sum over the (user block, item) lists; ') + '4-byte weight gathers')
     if n_slab:
         k['wmrb_combine'] = dict(rows=0, gather=0, hbm=n_slab * row32 + 2 * V_tab, roof='hbm', what='ordered sum of the per-block partial rows + fresh Adam')
     return k
@@ -289,7 +293,7 @@ def roofline_report(models, prof, pmc=None):
 
 # kernel symbol prefixes of the per-kernel timer names, for matching the committed PMC profile
 PMC_KERNELS = {'wmrb_scores': 'tmf::k_wmrb_scores3', 'wmrb_hinge': 'tmf::k_wmrb_hinge2', 'wmrb_gradu': 'tmf::k_wmrb_gradu3',
-               'wmrb_finish': 'tmf::k_wmrb_finish', 'wmrb_item_pass': 'tmf::k_wsum_pass', 'wmrb_combine': 'tmf::k_combine_rows',
+               'wmrb_finish': 'tmf::k_wmrb_finish', 'wmrb_item_pass': ('tmf::k_wsum_', ''), 'wmrb_combine': 'tmf::k_combine_rows',
                'wmrb_user_pass': 'tmf::k_wmrb_user',
                # the two launches per epoch of one kernel, told apart by dispatch order in tools/profile_summary.py
                'mse_user_pass': ('tmf::k_mse_pass', '[user pass]'), 'mse_item_pass': ('tmf::k_mse_pass', '[item pass]')}
@@ -619,11 +623,7 @@ class Workload:
             else:
                 self.R = random_sampler_device(n, m, S, seed=100 + rank, device=dev)
             trace('negative table drawn')
-            ns, sliced = _engine.choose_wmrb_user_pass(m, n, _lib.padded_ld(r, torch.bfloat16) if dtype == 'bf16' else ld, S, self.plan.n_pos, r,
-                                                       elem_size=2 if dtype == 'bf16' else 4)
-            rows4 = _engine.rows4_wanted(r, torch.bfloat16 if dtype == 'bf16' else torch.float32, self.plan, self.R)
-            self.wplan = _engine.WmrbPlan(self.plan, self.R, user_chunks=_engine.default_user_chunks(m, ld, n_items=None if rows4 else n),
-                                          item_slices=ns, n_components=r, sliced=sliced, rows4=rows4)
+            self.wplan = _engine.wmrb_plan_for(self.plan, self.R, r, torch.bfloat16 if dtype == 'bf16' else torch.float32)
         trace('WMRB plan built')
         self.st = _engine.TrainState(U0, V0, self.plan, r, self.wplan, dtype=torch.bfloat16 if dtype == 'bf16' else torch.float32)
         trace('training state allocated')
@@ -636,6 +636,11 @@ class Workload:
         st, p, w = self.st, self.plan, self.wplan
         s = 2 if self.dtype == 'bf16' else 4
         if self.loss == 'wmrb':
+            if w.rows4:   # row-stationary item pass: slab = the parts of the cut rows, one sweep of U per launch of resident lane groups
+                work = w.vrows.n_vrows if w.vrows is not None else self.n
+                return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced, int(w.rowptr_e[-1]),
+                                          w.vrows.n_slab if w.vrows is not None else 0, w.user_chunks, getattr(st, 'part_layers', None),
+                                          u_sweeps=max(2, -(-work // st.rows4_per_launch)))
             return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced,
                                       int(w.rowptr_e[-1]), w.seg_e.n_slab if w.seg_e is not None else 0, w.user_chunks,
                                       getattr(st, 'part_layers', None))

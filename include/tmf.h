@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TMF_VERSION 202 /* 0.2.2: tmf_slice_lists is 80 bytes (xcd_major, n_items), predict split / half2 / rows4 / gradu4 entry points */
+#define TMF_VERSION 203 /* 0.2.3: the balanced row-stationary item pass tmf_wsum_rows5; the 72-byte tmf_slice_lists carries `flags`: n_items counts only with TMF_SLICE_N_ITEMS_STATED */
 
 #define TMF_OK 0
 #define TMF_E_INVALID (-1)   /* bad argument (null pointer, unsupported rank, size mismatch) */
@@ -149,6 +149,21 @@ int tmf_wsum_rows4_f32(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, 
                        const float* wbuf, const float* T, const float* X_old, float* X_out, int n_components, int epi,
                        tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* BALANCED row-stationary form (round 5; speed only): what the lane groups own are VIRTUAL rows - (output row, part p of P), listed
+ * in (row, part) order - so that a row with far more list entries than the average (a popular item: one entry per user against
+ * 1,400 on average at config 5) is cut into P parts of about the average size and every lane group walks about the same number of
+ * entries.  In block t part p of row i takes the entries [b + p L / P, b + (p + 1) L / P) of that block's list [b, b + L).
+ *   vr_item / vr_part / vr_nparts [n_vrows + 1]: output row, part and number of parts of every virtual row; the last element is
+ *   the sentinel (n_rows, 0, 1);  vr_slot [n_vrows]: -1 = the row is whole (P = 1) and finished by the epilogue, else the slab slot
+ *   its partial sum goes to - the caller then finishes the cut rows with tmf_combine_rows: slots of a row consecutive, in part
+ *   order.  A fixed order of additions: results are bit-reproducible; against tmf_wsum_rows4 / tmf_wsum_pass equal to rounding.
+ * rows_per_launch counts virtual rows (a multiple of tmf_wsum_rows4_rows_per_group()). */
+size_t tmf_wsum_rows5_workspace_bytes(int32_t n_vrows, int32_t n_blocks, int32_t rows_per_launch);
+int tmf_wsum_rows5_f32(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row, const int32_t* ent_w,
+                       const float* wbuf, const float* T, const float* X_old, float* X_out, float* slab, const int32_t* vr_item,
+                       const int32_t* vr_part, const int32_t* vr_nparts, const int32_t* vr_slot, int32_t n_vrows, int n_components,
+                       int epi, tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Finishes the rows that tmf_*_pass cut into several segments: g[row] = sum of its slab slots
  * [slab_beg[i], slab_beg[i+1]) in order, then the epilogue. */
 int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
@@ -184,14 +199,23 @@ typedef struct tmf_slice_lists {
      * [slice_begin, slice_begin + slice_count) and the V pointer of the call addresses item row `item_base` (the first row
      * of the window).  All three 0 = the whole catalog. */
     int32_t slice_begin, slice_count, item_base;
-    /* Block order of the slice kernels (speed only): 0 = slice-major (every resident workgroup walks the same slice, each
-     * XCD L2 holds a copy of it), 1 = XCD-major (the XCD of block b - b mod 8 under the observed round-robin placement -
-     * walks the slices slice_begin + 8 i + (b mod 8): eight different slices resident, one per L2). */
-    int32_t xcd_major;
-    /* Items in the catalog the ids of R_sorted / col index (the rows of V), or 0 = not stated.  Speed only: when stated and
-     * n_items * row bytes < 2^32, tmf_wmrb_scores3 addresses V with 32-bit offsets (one instruction per row address). */
+    /* Bit set (this field was `xcd_major` = 0 | 1 up to version 202, so older callers keep their meaning):
+     *   TMF_SLICE_XCD_MAJOR (1)      block order of the slice kernels (speed only): clear = slice-major (every resident workgroup
+     *                                walks the same slice, each XCD L2 holds a copy of it), set = XCD-major (the XCD of block b - b mod 8
+     *                                under the observed round-robin placement - walks the slices slice_begin + 8 i + (b mod 8): eight
+     *                                different slices resident, one per L2);
+     *   TMF_SLICE_N_ITEMS_STATED (2) `n_items` below is meaningful.  The struct is 72 bytes: 5 pointers + 8 int32.  Up to version 201
+     *                                it ended after this field (68 bytes + 4 of tail padding), so a caller built against that
+     *                                header passes indeterminate bytes where n_items now sits: they are ignored unless this bit says
+     *                                the caller filled them in. */
+    int32_t flags;
+    /* Items in the catalog the ids of R_sorted / col index (the rows of V); counts only with TMF_SLICE_N_ITEMS_STATED.  Speed
+     * only: when stated and n_items * row bytes < 2^32, tmf_wmrb_scores3 addresses V with 32-bit offsets (one instruction per row
+     * address).  TMF_CHECK_IDS=1 in the environment makes the call verify (synchronously) that every id is below it. */
     int32_t n_items;
 } tmf_slice_lists;
+#define TMF_SLICE_XCD_MAJOR 1
+#define TMF_SLICE_N_ITEMS_STATED 2
 /* Kernels, called in this order on one stream (tables float (_f32) or bf16 (_bf16) rows as void*; sp / p / D / delta /
  * part / w_ent are fp32):
  *   tmf_wmrb_scores3_*  sp[u, s] = <U[u], V[R_sorted[u, s]]>, p[k] = <U[u_k], V[col[k]]>         (slice-major grid)
@@ -320,6 +344,10 @@ int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_row, const in
 int tmf_wsum_rows4_bf16(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row, const int32_t* ent_w,
                         const float* wbuf, const void* T, const void* X_old, void* X_out, int n_components, int epi,
                         tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream);
+int tmf_wsum_rows5_bf16(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row, const int32_t* ent_w,
+                        const float* wbuf, const void* T, const void* X_old, void* X_out, float* slab, const int32_t* vr_item,
+                        const int32_t* vr_part, const int32_t* vr_nparts, const int32_t* vr_slot, int32_t n_vrows, int n_components,
+                        int epi, tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream);
 int tmf_combine_rows_bf16(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,
                           const float* slab, const void* X_old, void* X_out, int n_components,
                           int epi, tmf_adam adam, void* stream);

@@ -282,26 +282,79 @@ def choose_wmrb_user_pass(n_users, n_items, ld, n_samples, n_positives, n_compon
     return 1, False
 
 
-def rows4_wanted(n_components, dtype=torch.float32, plan=None, R=None):
-    """The row-stationary item pass (tmf_wsum_rows4: lane groups own items and walk the user blocks, no slab, no combine) is
-    opt-in (TMF_ROWS4=1) and needs rows of at least 16 lanes; everything else takes tmf_wsum_pass + tmf_combine_rows.
-    It gives every lane group the same NUMBER of items, so a catalog with a few very popular items (power-law positives: the
-    top item of C4 has ~1M list entries against 11K on average) would leave a launch waiting for the lane groups that own
-    them - measured 1725 ms against 83 ms at the config-5 shard: with `plan` / `R` given, such catalogs are refused here."""
-    if os.environ.get('TMF_ROWS4') != '1':
+def rows4_wanted(n_components, dtype=torch.float32, plan=None, R=None, n_users=None, n_items=None):
+    """Which form the WMRB item pass takes: False = lists -> partial rows -> combine (tmf_wsum_pass + tmf_combine_rows: every
+    (user block, item) list writes one fp32 partial row into the slab), True = the ROW-STATIONARY form (lane groups own output rows,
+    keep their sums in registers and walk the user blocks; no slab, no combine - tmf_wsum_rows5, balanced over virtual rows so that
+    popular items are cut into parts, VirtualRows below).  Needs rows of at least 16 lanes.
+
+    Default: row-stationary exactly when the slab form cannot block the users for the L2s - its slab (user blocks x items x fp32
+    row) would exceed the budget at ~4 MB blocks, so the blocks grow (config-5 shard: 64 blocks of 10 MB, L2 hit rate 0.43, 128 GB
+    of slab traffic per epoch; profiles/r05_c5_item_pass.txt).  Where the slab fits (C4: 163 blocks, 8.3 GB) the slab form stays:
+    register-resident rows halve the waves per CU there (68 ms against 33, profiles/r03_c5_experiments.txt item 5).
+    TMF_ROWS4 = 1 | 0 forces the choice."""
+    env = os.environ.get('TMF_ROWS4')
+    if env == '0':
         return False
     if not _lib.load_library().tmf_wsum_rows4_rows_per_group(int(n_components), int(dtype is torch.bfloat16)):
         return False
-    if plan is not None and R is not None and plan.n_items:
-        per_item = torch.bincount(plan.col_u[plan.val_u > 0].to(torch.int64), minlength=plan.n_items)
-        per_item += torch.bincount(R.reshape(-1).to(torch.int64), minlength=plan.n_items)[:plan.n_items]
-        mean = float(per_item.to(torch.float64).mean())
-        if float(per_item.max()) > 4.0 * max(mean, 1.0):
-            import warnings
-            warnings.warn(f'row-stationary item pass (TMF_ROWS4) not used: the most popular item has {int(per_item.max())} list '
-                          f'entries against {mean:.0f} on average')
-            return False
-    return True
+    if env == '1':
+        return True
+    if plan is not None:
+        n_users = plan.n_users if n_users is None else n_users
+        n_items = plan.n_items if n_items is None else n_items
+    if not n_users or not n_items:
+        return False
+    ld = _lib.padded_ld(n_components, dtype)
+    row_bytes = ld * (2 if dtype is torch.bfloat16 else 4)
+    blocks_wanted = -(-int(n_users) * row_bytes // ROWS5_BLOCK_BYTES)          # user blocks of ~4 MB of rows as stored
+    blocks_slab_allows = max(1, _slab_budget() // (int(n_items) * ld * 4))     # one fp32 partial row per (block, item)
+    return blocks_wanted > 2 * blocks_slab_allows
+
+
+ROWS5_BLOCK_BYTES = 4 << 20   # user blocks of the row-stationary item pass (config-5 shard: 160 blocks of 4 MB 80.6 ms, 305 blocks 86.5)
+
+
+def rows5_user_chunks(n_users, n_components, dtype=torch.float32):
+    """User blocks of the row-stationary item pass: ~4 MB of U rows as stored, at most 256 (TMF_USER_CHUNKS overrides)."""
+    env = os.environ.get('TMF_USER_CHUNKS')
+    if env:
+        return max(1, int(env))
+    row_bytes = _lib.padded_ld(n_components, dtype) * (2 if dtype is torch.bfloat16 else 4)
+    return int(min(max(1, -(-int(n_users) * row_bytes // ROWS5_BLOCK_BYTES)), 256))
+
+
+class VirtualRows:
+    """Work units of tmf_wsum_rows5 (include/tmf.h): output row i with cnt_i list entries (all user blocks together) is cut into
+    P_i = ceil(cnt_i / target) parts, target = 1.5 x the mean (TMF_ROWS5_TARGET overrides): the ordinary rows stay whole, the
+    popular ones become parts of about the mean size, and a lane group's K consecutive virtual rows carry about K x mean entries
+    whatever the popularity of its items.  Cut rows get consecutive slab slots (part order) and are finished by tmf_combine_rows."""
+
+    def __init__(self, rowptr_e, n_blocks, n_rows, target=None):
+        dev = rowptr_e.device
+        lens = (rowptr_e[1:] - rowptr_e[:-1]).view(n_blocks, n_rows).sum(0)                       # entries of every output row
+        mean = float(lens.to(torch.float64).mean()) if n_rows else 0.0
+        env = os.environ.get('TMF_ROWS5_TARGET')
+        self.target = int(env) if env else (int(target) if target else max(1, int(1.5 * mean) + 1))
+        parts = torch.clamp((lens + (self.target - 1)) // self.target, min=1)
+        first = _excl_cumsum(parts)                                                               # first virtual row of every row
+        nv = int(first[-1])
+        item = torch.repeat_interleave(torch.arange(n_rows, device=dev), parts, output_size=nv)
+        part = torch.arange(nv, device=dev) - first[item]
+        multi = parts > 1
+        slab_beg = _excl_cumsum(parts * multi)
+        slot = torch.where(multi[item], slab_beg[item] + part, torch.full_like(part, -1))
+        i32 = torch.int32
+        self.n_vrows, self.n_slab = nv, int(slab_beg[-1])
+        self.item = torch.cat([item, torch.tensor([n_rows], device=dev)]).to(i32).contiguous()   # + the sentinel (n_rows, 0, 1)
+        self.part = torch.cat([part, torch.zeros(1, dtype=part.dtype, device=dev)]).to(i32).contiguous()
+        self.nparts = torch.cat([parts[item], torch.ones(1, dtype=parts.dtype, device=dev)]).to(i32).contiguous()
+        self.slot = slot.to(i32).contiguous()
+        long_rows = torch.nonzero(multi).flatten()
+        self.long_rows = long_rows.to(i32).contiguous()
+        self.long_slab_beg = torch.cat([slab_beg[long_rows], slab_beg[-1:]]).contiguous()
+        self.n_long = int(long_rows.numel())
+        self.max_parts = int(parts.max()) if n_rows else 0
 
 
 def fused_user_pass_fits(n_samples, n_components):
@@ -408,6 +461,8 @@ class WmrbPlan:
         self.rowptr_e = rowptr[:C * n + 1].contiguous()  # the row behind them holds the stored values <= 0: never read
         self.ent_w = ent_id
         self.rows4 = bool(rows4)
+        # the row-stationary item pass walks VIRTUAL rows (popular items cut into parts); TMF_ROWS5=0: the plain form (tmf_wsum_rows4)
+        self.vrows = VirtualRows(self.rowptr_e, C, n) if self.rows4 and os.environ.get('TMF_ROWS5', '1') != '0' else None
         if not item_lists or self.rows4:
             self.seg_e = None   # the caller cuts the lists into windows itself (SegmentTable.of_rows) / row-stationary item pass
         elif C > 1:
@@ -428,7 +483,7 @@ class WmrbPlan:
             m, S = self.R.shape
             self._lists = _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(),
                                           plan.col_u.data_ptr(), self.pos_off.data_ptr(), m, S, self.n_slices, 0, 0, 0,
-                                          int(self.xcd_major), int(plan.n_items))
+                                          (_lib.SLICE_XCD_MAJOR if self.xcd_major else 0) | _lib.SLICE_N_ITEMS_STATED, int(plan.n_items))
         return ctypes.byref(self._lists)
 
     def window_lists(self, plan, slice_begin, slice_count, item_base):
@@ -436,8 +491,8 @@ class WmrbPlan:
         from item_base on (item-row-sharded V).  The caller keeps the returned struct alive."""
         m, S = self.R.shape
         return _lib.SliceLists(self.R.data_ptr(), self.slice_off.data_ptr(), plan.rowptr_u.data_ptr(), plan.col_u.data_ptr(),
-                               self.pos_off.data_ptr(), m, S, self.n_slices, slice_begin, slice_count, item_base, 0,
-                               int(plan.n_items))
+                               self.pos_off.data_ptr(), m, S, self.n_slices, slice_begin, slice_count, item_base,
+                               _lib.SLICE_N_ITEMS_STATED, int(plan.n_items))
 
     def D_in_model_order(self):
         """D[u, s] indexed like the model's random_ind (the sliced pass keeps every user's negatives sorted by item)."""
@@ -447,6 +502,20 @@ class WmrbPlan:
         out = torch.empty_like(self.D)
         out.scatter_(1, perm, self.D)
         return out
+
+
+def wmrb_plan_for(plan, R, n_components, dtype=torch.float32, n_items=None):
+    """The WmrbPlan a fit builds for (plan, R): the user-pass form (choose_wmrb_user_pass), the item-pass form (rows4_wanted) and the
+    user blocks that go with it - ONE place for MatrixFactorization._fit_sparse, dist.fit_data_parallel and bench.py.
+    n_items: the catalog size for the slice geometry when the plan's table is padded (multi-GPU: rows padded to the world size)."""
+    m = plan.n_users
+    n = plan.n_items if n_items is None else n_items
+    bf16 = dtype is torch.bfloat16
+    ld_store = _lib.padded_ld(n_components, dtype)
+    ns, sliced = choose_wmrb_user_pass(m, n, ld_store, int(R.shape[1]), plan.n_pos, n_components, elem_size=2 if bf16 else 4)
+    rows4 = rows4_wanted(n_components, dtype, plan, R)
+    C = rows5_user_chunks(m, n_components, dtype) if rows4 else default_user_chunks(m, _lib.padded_ld(n_components), n_items=plan.n_items)
+    return WmrbPlan(plan, R, user_chunks=C, item_slices=ns, n_components=n_components, sliced=sliced, rows4=rows4)
 
 
 def scores5_wanted(plan, wplan, n_components, dtype=torch.float32):
@@ -568,7 +637,8 @@ class TrainState:
             self.V, self.V_nxt = V_tables
         self.plan, self.wplan = plan, wplan
         need = dict(slab=max(plan.seg_u.n_slab, plan.seg_i.n_slab if plan.seg_i else 0,
-                             wplan.seg_e.n_slab if wplan is not None and wplan.seg_e is not None else 0, 1) * self.ld,
+                             wplan.seg_e.n_slab if wplan is not None and wplan.seg_e is not None else 0,
+                             wplan.vrows.n_slab if wplan is not None and getattr(wplan, 'vrows', None) is not None else 0, 1) * self.ld,
                     loss_part=max(plan.seg_u.nseg, plan.n_users, 1))
         self.row_stationary = False
         if wplan is not None and wplan.sliced:
@@ -601,7 +671,8 @@ class TrainState:
                 raise ValueError('the row-stationary item pass needs rows of at least 16 lanes')
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if torch.cuda.is_available() else 256
             self.rows4_per_launch = int(os.environ.get('TMF_ROWS4_PER_LAUNCH', 2 * cus * per_group))   # two workgroups per CU resident
-            nb = L.tmf_wsum_rows4_workspace_bytes(plan.n_items, wplan.user_chunks, self.rows4_per_launch)
+            n_work = wplan.vrows.n_vrows if wplan.vrows is not None else plan.n_items
+            nb = L.tmf_wsum_rows4_workspace_bytes(n_work, wplan.user_chunks, self.rows4_per_launch)
             self.rows4_sync = torch.zeros(max(nb // 4, 1), dtype=torch.int32, device=dev)
         self._need = need
         if scratch is None:
@@ -761,17 +832,33 @@ def epoch_wmrb(st, adam, c, loss_out, item_epi=_lib.EPI_ADAM, item_out=None, pro
     _lib.check(lib.tmf_sum_f32(_lib.ptr(st.loss_part), p.n_users, _lib.ptr(loss_out), s), lib)
     V_out = st.V_nxt if item_out is None else item_out
     if w.rows4:
-        # row-stationary item pass: lane groups own items and walk the user blocks; no slab, no combine
+        # row-stationary item pass: lane groups own (virtual) rows and walk the user blocks; no slab but for the parts of cut rows
         if prof:
             prof.start('wmrb_item_pass')
-        n_rows = st.V.shape[0]
-        _lib.check(getattr(lib, 'tmf_wsum_rows4' + st.sfx)(_lib.ptr(w.rowptr_e), ctypes.c_int32(p.n_items), ctypes.c_int32(w.user_chunks),
-                                                           _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf), _lib.ptr(st.U),
-                                                           _lib.ptr(st.V), _lib.ptr(V_out), r, item_epi, adam,
-                                                           ctypes.c_int32(st.rows4_per_launch), _lib.ptr(st.rows4_sync),
-                                                           st.rows4_sync.numel() * 4, s), lib)
+        i32 = ctypes.c_int32
+        if w.vrows is not None:
+            v = w.vrows
+            _lib.check(getattr(lib, 'tmf_wsum_rows5' + st.sfx)(_lib.ptr(w.rowptr_e), i32(p.n_items), i32(w.user_chunks), _lib.ptr(w.ent_row),
+                                                               _lib.ptr(w.ent_w), _lib.ptr(w.wbuf), _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(V_out),
+                                                               _lib.ptr(st.slab), _lib.ptr(v.item), _lib.ptr(v.part), _lib.ptr(v.nparts),
+                                                               _lib.ptr(v.slot), i32(v.n_vrows), r, item_epi, adam, i32(st.rows4_per_launch),
+                                                               _lib.ptr(st.rows4_sync), st.rows4_sync.numel() * 4, s), lib)
+        else:
+            _lib.check(getattr(lib, 'tmf_wsum_rows4' + st.sfx)(_lib.ptr(w.rowptr_e), i32(p.n_items), i32(w.user_chunks),
+                                                               _lib.ptr(w.ent_row), _lib.ptr(w.ent_w), _lib.ptr(w.wbuf), _lib.ptr(st.U),
+                                                               _lib.ptr(st.V), _lib.ptr(V_out), r, item_epi, adam,
+                                                               i32(st.rows4_per_launch), _lib.ptr(st.rows4_sync),
+                                                               st.rows4_sync.numel() * 4, s), lib)
         if prof:
             prof.stop('wmrb_item_pass')
+        if w.vrows is not None and w.vrows.n_long:
+            if prof:
+                prof.start('wmrb_combine')
+            v = w.vrows
+            _lib.check(getattr(lib, 'tmf_combine_rows' + st.sfx)(_lib.ptr(v.long_rows), _lib.ptr(v.long_slab_beg), v.n_long, _lib.ptr(st.slab),
+                                                                 _lib.ptr(st.V), _lib.ptr(V_out), r, item_epi, adam, s), lib)
+            if prof:
+                prof.stop('wmrb_combine')
         return
     if prof:
         prof.start('wmrb_item_pass')

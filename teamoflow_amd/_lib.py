@@ -33,7 +33,7 @@ class SliceLists(ctypes.Structure):
     _fields_ = [('R_sorted', ctypes.c_void_p), ('slice_off', ctypes.c_void_p), ('rowptr', ctypes.c_void_p),
                 ('col', ctypes.c_void_p), ('pos_off', ctypes.c_void_p), ('n_users', ctypes.c_int32),
                 ('n_samples', ctypes.c_int32), ('n_slices', ctypes.c_int32), ('slice_begin', ctypes.c_int32),
-                ('slice_count', ctypes.c_int32), ('item_base', ctypes.c_int32), ('xcd_major', ctypes.c_int32),
+                ('slice_count', ctypes.c_int32), ('item_base', ctypes.c_int32), ('flags', ctypes.c_int32),
                 ('n_items', ctypes.c_int32)]
 
 
@@ -71,6 +71,8 @@ _BASE_SIGNATURES = {
     'tmf_wsum_rows4_rows_per_group': (_I, [_I, _I]),
     'tmf_wsum_rows4_workspace_bytes': (_SZ, [_I32, _I32, _I32]),
     'tmf_wsum_rows4_f32': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _I32, _P, _SZ, _P]),
+    'tmf_wsum_rows5_workspace_bytes': (_SZ, [_I32, _I32, _I32]),
+    'tmf_wsum_rows5_f32': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I, _I, Adam, _I32, _P, _SZ, _P]),
     'tmf_combine_rows_f32': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_fits': (_I, [_I32, _I]),
@@ -91,6 +93,7 @@ _BASE_SIGNATURES = {
     'tmf_adam_state_rows_f32': (_I, [_P, _P, _P, _P, _L, _I, Adam, _P]),
     'tmf_mse_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wsum_rows4_bf16': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _I32, _P, _SZ, _P]),
+    'tmf_wsum_rows5_bf16': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I, _I, Adam, _I32, _P, _SZ, _P]),
     'tmf_wsum_pass_bf16': (_I, [_SEG, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_combine_rows_bf16': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_bf16': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
@@ -115,7 +118,8 @@ for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_scores5', 'tmf_wmrb_gradu3', 'tmf_wm
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name + '_f32']
 
 _lib = None
-MIN_LIB_VERSION = 202   # include/tmf.h TMF_VERSION: 202 = tmf_slice_lists is 80 bytes (xcd_major, n_items) + the round-3 entry points
+MIN_LIB_VERSION = 203   # include/tmf.h TMF_VERSION: 203 = tmf_wsum_rows5, tmf_slice_lists.flags (72-byte struct; n_items counts only with SLICE_N_ITEMS_STATED)
+SLICE_XCD_MAJOR, SLICE_N_ITEMS_STATED = 1, 2   # tmf_slice_lists.flags
 
 
 def build(force=False, verbose=False):

@@ -311,11 +311,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) TMF_WSUM_OCC void k_wsum_pass_
 // ---------------------------------------------------------------------------------------------
 constexpr int kRows4Tile = 64;
 
+// BALANCED form ("rows5", round 5): the rows a lane group owns are VIRTUAL rows - (output row, part p of P) - listed in (row, part)
+// order, so that a popular item (C4 / config 5: the top item has one list entry per user, the average 1,400) is cut into P parts
+// of about the average size and every lane group walks about the same number of entries: in block t part p of row i takes the
+// entries [b + p L / P, b + (p + 1) L / P) of that block's list [b, b + L) of the row.  Consecutive virtual rows are consecutive
+// parts of one row or consecutive rows, so the K virtual rows of a lane group are still ONE contiguous range of entries in every
+// block.  A row with P = 1 is finished by its lane group (epilogue); the parts of a cut row go to slab slots and
+// tmf_combine_rows adds them in part order - a fixed order, so the result is bit-reproducible.  vr.item == nullptr: the plain
+// form above (virtual row v = output row v).
+struct VRows {
+    const int32_t* item;     // [n_vrows + 1] output row of every virtual row; item[n_vrows] = n_rows (the end of a block's lists)
+    const int32_t* part;     // [n_vrows + 1] part index, 0 for the sentinel
+    const int32_t* nparts;   // [n_vrows + 1] parts of that row, 1 for the sentinel
+    const int32_t* slot;     // [n_vrows] slab slot of a part of a cut row, -1 = the whole row: epilogue
+    float* slab;
+};
+
 template <int G, int NV, typename T, int K, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wsum_rows4(
     const int64_t* __restrict__ rowptr, int64_t n_rows, int n_blocks, const int32_t* __restrict__ ent_row,
     const int32_t* __restrict__ ent_w, const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
-    void* __restrict__ X_out, int epi, tmf_adam adam, int64_t row_begin, int64_t row_end, int* __restrict__ sync, int lag) {
+    void* __restrict__ X_out, int epi, tmf_adam adam, int64_t row_begin, int64_t row_end, int* __restrict__ sync, int lag,
+    VRows vr) {
     static_assert(K + 1 <= G, "the list boundaries of a block live in one register of the lane group");
     constexpr int NG = 64 / G, NGB = NG * WAVES;
     __shared__ int s_ids[NGB][kRows4Tile];
@@ -329,9 +346,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wsum_rows4(
     Frag<NV> acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) zero<NV>(acc[k]);
+    // lane l <= kv describes the boundary "first entry of (virtual) row j0 + l"; lanes beyond kv repeat the last one
+    const bool balanced = vr.item != nullptr;
+    const int64_t vq = j0 + (g < kv ? g : kv);
+    const int64_t it = (balanced && kv > 0) ? (int64_t)vr.item[vq] : vq;
+    const int pt = (balanced && kv > 0) ? vr.part[vq] : 0, np = (balanced && kv > 0) ? vr.nparts[vq] : 1;
     for (int t = 0; t < n_blocks; ++t) {
-        // lane l <= kv: first entry of the list (block t, row j0 + l); entries fit 31 bits (include/tmf.h)
-        const int bnd = (kv > 0) ? (int)rowptr[(int64_t)t * n_rows + j0 + (g < kv ? g : kv)] : 0;
+        // entries fit 31 bits (include/tmf.h); a cut row: its part's share of this block's list
+        int bnd = 0;
+        if (kv > 0) {
+            const int64_t lb = rowptr[(int64_t)t * n_rows + it];
+            bnd = (int)lb;
+            if (np > 1) bnd += (int)(((int64_t)pt * (rowptr[(int64_t)t * n_rows + it + 1] - lb)) / np);
+        }
         const int r_beg = group_read<G>(bnd, 0), r_end = group_read<G>(bnd, kv);
         int b[K + 1];
 #pragma unroll
@@ -370,8 +397,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wsum_rows4(
         __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (k < kv) row_epilogue<G, NV, T>(acc[k], X_old, X_out, j0 + k, g, epi, adam);
+    for (int k = 0; k < K; ++k) {
+        const int64_t row = group_read<G>((int)it, k < kv ? k : 0);   // every lane of the wave takes part in the exchange
+        if (k >= kv) continue;
+        const int slot = balanced ? vr.slot[j0 + k] : -1;
+        if (slot < 0) row_epilogue<G, NV, T>(acc[k], X_old, X_out, row, g, epi, adam);
+        else store_row_f32<G, NV, T>(acc[k], vr.slab, slot, g);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,8 +651,14 @@ extern "C" int tmf_wsum_pass_bf16(const tmf_segments* seg, const int32_t* ent_ro
 template <typename T>
 static int wsum_rows4_impl(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row, const int32_t* ent_w,
                            const float* wbuf, const void* Tab, const void* X_old, void* X_out, int n_components, int epi,
-                           tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream) {
+                           tmf_adam adam, int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream,
+                           VRows vr = VRows{nullptr, nullptr, nullptr, nullptr, nullptr}, int32_t n_vrows = 0) {
     if (n_rows == 0) return TMF_OK;
+    if (vr.item != nullptr) {
+        TMF_REQUIRE(vr.part && vr.nparts && vr.slot && n_vrows >= n_rows, "wsum_rows5: virtual rows: null array or %d virtual rows for %d rows",
+                    n_vrows, n_rows);
+    }
+    const int64_t n_work = vr.item != nullptr ? n_vrows : n_rows;   // what the lane groups own: virtual rows, or the rows themselves
     TMF_REQUIRE(n_rows > 0 && n_blocks > 0 && rows_per_launch > 0, "wsum_rows4: n_rows=%d n_blocks=%d rows_per_launch=%d", n_rows,
                 n_blocks, rows_per_launch);
     TMF_REQUIRE(rowptr && ent_row && ent_w && wbuf && Tab && X_out && (epi == TMF_EPI_GRAD || X_old), "wsum_rows4: null pointer");
@@ -633,7 +671,7 @@ static int wsum_rows4_impl(const int64_t* rowptr, int32_t n_rows, int32_t n_bloc
     constexpr int W4 = 8;
     const int K4 = geom.NV >= 2 ? 8 : 15;   // rows per lane group: 8 x 8 or 15 x 4 accumulator registers
     const int64_t per_block = (int64_t)(64 / geom.G) * W4 * K4;
-    const int64_t launches = ((int64_t)n_rows + rows_per_launch - 1) / rows_per_launch;
+    const int64_t launches = (n_work + rows_per_launch - 1) / rows_per_launch;
     int* sync = nullptr;
     int lag = 1;
     if (const char* env = getenv("TMF_G4_LAG")) lag = atoi(env);
@@ -643,14 +681,14 @@ static int wsum_rows4_impl(const int64_t* rowptr, int32_t n_rows, int32_t n_bloc
         if (hipMemsetAsync(workspace, 0, need, (hipStream_t)stream) != hipSuccess) { set_error("wsum_rows4: hipMemsetAsync failed"); return TMF_E_LAUNCH; }
         sync = static_cast<int*>(workspace);
     }
-    for (int64_t b = 0, launch = 0; b < n_rows; b += rows_per_launch, ++launch) {
-        const int64_t e = (b + rows_per_launch < n_rows) ? b + rows_per_launch : n_rows;
+    for (int64_t b = 0, launch = 0; b < n_work; b += rows_per_launch, ++launch) {
+        const int64_t e = (b + rows_per_launch < n_work) ? b + rows_per_launch : n_work;
         const unsigned blocks = (unsigned)((e - b + per_block - 1) / per_block);
         int* sy = sync ? sync + launch * n_blocks * 8 * kSyncStride : nullptr;
 #define CALLK(G_, NV_, K_)                                                                                                     \
     hipLaunchKernelGGL((k_wsum_rows4<G_, NV_, T, K_, W4>), dim3(blocks), dim3(64 * W4), 0, (hipStream_t)stream, rowptr,          \
                        (int64_t)n_rows, (int)n_blocks, ent_row, ent_w, wbuf, (const T*)Tab, (const T*)X_old, X_out, epi, adam, b, \
-                       e, sy, lag)
+                       e, sy, lag, vr)
         if constexpr (std::is_same<T, float>::value) {
             if (geom.NV == 1 && geom.G == 16) { CALLK(16, 1, 15); }
             else if (geom.NV == 1 && geom.G == 32) { CALLK(32, 1, 15); }
@@ -689,6 +727,30 @@ extern "C" int tmf_wsum_rows4_bf16(const int64_t* rowptr, int32_t n_rows, int32_
                                    size_t workspace_bytes, void* stream) {
     return wsum_rows4_impl<__bf16>(rowptr, n_rows, n_blocks, ent_row, ent_w, wbuf, T, X_old, X_out, n_components, epi, adam,
                                    rows_per_launch, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t tmf_wsum_rows5_workspace_bytes(int32_t n_vrows, int32_t n_blocks, int32_t rows_per_launch) {
+    return rows_per_launch > 0 ? rendezvous_bytes(((int64_t)n_vrows + rows_per_launch - 1) / rows_per_launch, n_blocks) : 0;
+}
+extern "C" int tmf_wsum_rows5_f32(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row,
+                                  const int32_t* ent_w, const float* wbuf, const float* T, const float* X_old, float* X_out,
+                                  float* slab, const int32_t* vr_item, const int32_t* vr_part, const int32_t* vr_nparts,
+                                  const int32_t* vr_slot, int32_t n_vrows, int n_components, int epi, tmf_adam adam,
+                                  int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream) {
+    TMF_REQUIRE(vr_item != nullptr, "wsum_rows5: vr_item is null (tmf_wsum_rows4 is the form without virtual rows)");
+    return wsum_rows4_impl<float>(rowptr, n_rows, n_blocks, ent_row, ent_w, wbuf, T, X_old, X_out, n_components, epi, adam,
+                                  rows_per_launch, workspace, workspace_bytes, stream, VRows{vr_item, vr_part, vr_nparts, vr_slot, slab},
+                                  n_vrows);
+}
+extern "C" int tmf_wsum_rows5_bf16(const int64_t* rowptr, int32_t n_rows, int32_t n_blocks, const int32_t* ent_row,
+                                   const int32_t* ent_w, const float* wbuf, const void* T, const void* X_old, void* X_out,
+                                   float* slab, const int32_t* vr_item, const int32_t* vr_part, const int32_t* vr_nparts,
+                                   const int32_t* vr_slot, int32_t n_vrows, int n_components, int epi, tmf_adam adam,
+                                   int32_t rows_per_launch, void* workspace, size_t workspace_bytes, void* stream) {
+    TMF_REQUIRE(vr_item != nullptr, "wsum_rows5: vr_item is null (tmf_wsum_rows4 is the form without virtual rows)");
+    return wsum_rows4_impl<__bf16>(rowptr, n_rows, n_blocks, ent_row, ent_w, wbuf, T, X_old, X_out, n_components, epi, adam,
+                                   rows_per_launch, workspace, workspace_bytes, stream, VRows{vr_item, vr_part, vr_nparts, vr_slot, slab},
+                                   n_vrows);
 }
 
 extern "C" int tmf_combine_rows_f32(const int32_t* long_rows, const int64_t* slab_beg, int64_t n_long,

@@ -881,14 +881,45 @@ static int check_lists(const tmf_slice_lists* l, SliceLists& a, const char* what
     const int sl0 = l->slice_begin, nsl = l->slice_count > 0 ? l->slice_count : l->n_slices - sl0;
     TMF_REQUIRE(sl0 >= 0 && nsl > 0 && sl0 + nsl <= l->n_slices && l->item_base >= 0, "%s: window [%d, +%d) of %d slices, item_base=%d",
                 what, sl0, l->slice_count, l->n_slices, l->item_base);
-    int xcd = l->xcd_major != 0;
+    int xcd = (l->flags & TMF_SLICE_XCD_MAJOR) != 0;
     if (const char* env = getenv("TMF_SLICE_XCD")) xcd = env[0] == '1';   // A/B runs
     // the lean scores walk addresses V with 32-bit byte offsets: only when the caller says how many items there are (n_items = 0:
     // not stated) and they fit; TMF_LEAN=0 forces the general form (A/B runs, tests)
-    int lean = l->n_items > 0 && row_bytes > 0 && (int64_t)l->n_items * (int64_t)row_bytes < ((int64_t)1 << 32);
+    int lean = (l->flags & TMF_SLICE_N_ITEMS_STATED) && l->n_items > 0 && row_bytes > 0 && (int64_t)l->n_items * (int64_t)row_bytes < ((int64_t)1 << 32);
     if (const char* env = getenv("TMF_LEAN")) lean = lean && env[0] != '0';
     a = SliceLists{l->R_sorted, l->slice_off, l->rowptr, l->col, l->pos_off, l->n_slices, l->n_samples, l->n_users, groups,
                    upg, sl0, nsl, l->item_base, xcd, lean};
+    return TMF_OK;
+}
+
+// TMF_CHECK_IDS=1 (debug): every id of the lists really is below the n_items the caller stated - the lean walk addresses V with
+// 32-bit offsets on the strength of that number.  Synchronous, allocates a flag: never on by default.
+namespace tmf {
+__global__ __launch_bounds__(256) void k_check_ids(const int32_t* __restrict__ R, int64_t n_neg, const int32_t* __restrict__ col,
+                                                   const int64_t* __restrict__ rowptr, int64_t n_users, int n_items, int* __restrict__ bad) {
+    const int64_t nnz = col ? rowptr[n_users] : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_neg + nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const int id = i < n_neg ? R[i] : col[i - n_neg];
+        if (id < 0 || id >= n_items) atomicAdd(bad, 1);
+    }
+}
+}  // namespace tmf
+static int check_ids_debug(const tmf_slice_lists* l, hipStream_t stream) {
+    const char* env = getenv("TMF_CHECK_IDS");
+    if (!(env && env[0] == '1') || !(l->flags & TMF_SLICE_N_ITEMS_STATED) || l->n_users == 0) return TMF_OK;
+    int* bad = nullptr;
+    int host = 0;
+    if (hipMalloc(&bad, sizeof(int)) != hipSuccess || hipMemsetAsync(bad, 0, sizeof(int), stream) != hipSuccess) {
+        set_error("TMF_CHECK_IDS: could not allocate the flag");
+        return TMF_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(tmf::k_check_ids, dim3(1024), dim3(256), 0, stream, l->R_sorted, (int64_t)l->n_users * l->n_samples, l->col,
+                       l->rowptr, (int64_t)l->n_users, (int)l->n_items, bad);
+    const bool ok = hipMemcpyAsync(&host, bad, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                    hipStreamSynchronize(stream) == hipSuccess;
+    (void)hipFree(bad);
+    if (!ok) { set_error("TMF_CHECK_IDS: the check itself failed"); return TMF_E_LAUNCH; }
+    TMF_REQUIRE(host == 0, "tmf_slice_lists: %d ids of R_sorted / col are outside [0, n_items = %d)", host, l->n_items);
     return TMF_OK;
 }
 
@@ -919,6 +950,7 @@ static int wmrb_scores3_impl(const tmf_slice_lists* lists, const void* U, const 
     const int waves = slice_waves(lists, geom.G);
     if (int rc = check_lists(lists, a, "wmrb_scores3", geom.G, waves, (size_t)geom.ld * sizeof(T))) return rc;
     if (a.n_users == 0) return TMF_OK;
+    if (int rc = check_ids_debug(lists, (hipStream_t)stream)) return rc;
     TMF_REQUIRE(U && V && sp && (p || lists->col == nullptr), "wmrb_scores3: null pointer");
     const size_t lds = slice_lds(geom, waves);
     // one launch carries < 2^32 work-items: many slices x many user groups go out in several launches of whole slices

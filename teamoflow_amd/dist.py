@@ -505,10 +505,7 @@ def fit_data_parallel(model, epochs, n_users, n_items, interactions, lr, U0, V0,
         if R.numel() and (int(R.min()) < 0 or int(R.max()) >= n_items):
             raise IndexError('random_ind holds item ids outside [0, n_items)')
         c = model.n_items / model.n_samples
-        ns, sliced = _engine.choose_wmrb_user_pass(e - b, n_pad, ld, int(R.shape[1]), plan.n_pos, model.n_components,
-                                                   elem_size=2 if model.factor_dtype is torch.bfloat16 else 4)
-        wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(e - b, ld, n_items=n_pad),
-                                 item_slices=ns, n_components=model.n_components, sliced=sliced)
+        wplan = _engine.wmrb_plan_for(plan, R, model.n_components, model.factor_dtype)
     V0p = torch.zeros(n_pad, model.n_components, dtype=torch.float32, device=dev)
     V0p[:n_items] = torch.as_tensor(V0).detach().to(device=dev, dtype=torch.float32)
     U_blk = torch.as_tensor(U0).detach() if local is not None else torch.as_tensor(U0).detach()[b:e]

@@ -172,13 +172,7 @@ class MatrixFactorization:
             if R.numel() and (int(R.min()) < 0 or int(R.max()) >= n_items):
                 raise IndexError('random_ind holds item ids outside [0, n_items)')
             c = self.n_items / self.n_samples  # constructor ints, true division (:167)
-            bf16 = self.factor_dtype is torch.bfloat16
-            ns, sliced = _engine.choose_wmrb_user_pass(n_users, n_items, _lib.padded_ld(self.n_components, self.factor_dtype), int(R.shape[1]),
-                                                       plan.n_pos, self.n_components, elem_size=2 if bf16 else 4)
-            rows4 = _engine.rows4_wanted(self.n_components, self.factor_dtype, plan, R)   # no slab: the block count is not capped by it
-            wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(n_users, _lib.padded_ld(self.n_components),
-                                                                                      n_items=None if rows4 else n_items),
-                                     item_slices=ns, n_components=self.n_components, sliced=sliced, rows4=rows4)
+            wplan = _engine.wmrb_plan_for(plan, R, self.n_components, self.factor_dtype)
         st = _engine.TrainState(U0, V0, plan, self.n_components, wplan, dtype=self.factor_dtype)
         adam = _engine.adam_constants(lr)
         loss_sums = torch.zeros(max(epochs, 1), dtype=torch.float64, device=dev)

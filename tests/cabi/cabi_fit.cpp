@@ -53,7 +53,7 @@ int main() {
     const int m = 300, n = 200, r = 24, epochs = 5, k = 5;
     const float lr = 1e-3f;
     const int ld = tmf_padded_ld(r);
-    if (tmf_version() < 202 || ld < r) { fprintf(stderr, "library version %d, ld %d\n", tmf_version(), ld); return 1; }
+    if (tmf_version() < 203 || ld < r) { fprintf(stderr, "library version %d, ld %d\n", tmf_version(), ld); return 1; }
     Lcg rng{12345};
     std::set<std::pair<int, int>> seen;
     std::vector<int64_t> idx;
@@ -178,7 +178,7 @@ int main() {
         tmf_segments seg_e{d_rowptr_e, dev_copy(seg_row), dev_copy(seg_chunk), dev_copy(seg_slab), (int64_t)C * n, 1024, 0};
         int32_t* d_items = dev_copy(items);
         int64_t* d_slab_beg = dev_copy(slab_beg);
-        tmf_slice_lists lists{d_Rs, d_off, d_rowptr_u, d_col_u, d_poff, m, S, ns, 0, 0, 0, 0, n};   // n_items stated
+        tmf_slice_lists lists{d_Rs, d_off, d_rowptr_u, d_col_u, d_poff, m, S, ns, 0, 0, 0, TMF_SLICE_N_ITEMS_STATED, n};
         float *d_sp, *d_pk, *d_wbuf, *d_part, *d_slab2, *d_lp2;
         HIP_OK(hipMalloc(&d_sp, (size_t)m * S * 4)); HIP_OK(hipMalloc(&d_pk, nnz * 4)); HIP_OK(hipMalloc(&d_wbuf, E * 4));
         HIP_OK(hipMalloc(&d_part, (size_t)ns * m * ld * 4)); HIP_OK(hipMalloc(&d_slab2, (size_t)C * n * ld * 4)); HIP_OK(hipMalloc(&d_lp2, m * 4));

@@ -48,9 +48,10 @@ def c5():
     ld = _lib.padded_ld(r)   # the plans are sized like MatrixFactorization._fit_sparse sizes them
     plan = _engine.InteractionPlan(idx, val, m, n, csc=False)
     R = random_sampler_device(n, m, S, seed=100, device=dev)
-    wplan = _engine.WmrbPlan(plan, R, user_chunks=_engine.default_user_chunks(m, ld, n_items=n),
-                             item_slices=_engine.default_item_slices(n, ld), n_components=r)
+    wplan = _engine.wmrb_plan_for(plan, R, r, torch.bfloat16)     # the plan MatrixFactorization._fit_sparse builds at this shape
     assert wplan.user_chunks > 1 and wplan.n_slices > 1
+    # this is the shape the balanced row-stationary item pass (tmf_wsum_rows5) is the default for: the popular items are cut
+    assert wplan.rows4 and wplan.vrows is not None and wplan.vrows.n_long > 0 and wplan.vrows.max_parts > 50
     st = _engine.TrainState(U0.float(), V0.float(), plan, r, wplan, dtype=torch.bfloat16)
     assert torch.equal(st.U[:, :r], U0) and torch.equal(st.V[:, :r], V0)
     adam = _engine.adam_constants(lr)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tmf_version() == 202 == _lib.MIN_LIB_VERSION
+    assert lib.tmf_version() == 203 == _lib.MIN_LIB_VERSION
 
 
 def test_padded_ld_and_adam_constants_match_host_mirror():
@@ -261,3 +261,39 @@ def test_half2_range_guard_on_cpu():
     assert not _ops.half2_range_ok(V)
     assert _ops.split_topk_supported(128, 32) and not _ops.split_topk_supported(129, 1)
     assert _ops.half2_topk_supported(256, 32) and not _ops.half2_topk_supported(257, 1) and not _ops.half2_topk_supported(8, 33)
+
+
+def test_virtual_rows_of_the_balanced_item_pass():
+    """_engine.VirtualRows (work units of tmf_wsum_rows5): every output row is cut into ceil(entries / target) parts, the virtual
+    rows are listed in (row, part) order with a sentinel behind them, whole rows have slot -1, the parts of a cut row consecutive
+    slab slots in part order - what tmf_combine_rows sums."""
+    import torch
+    from teamoflow_amd import _engine as E
+    C, n = 3, 7
+    lens = torch.tensor([[0, 5, 1, 40, 2, 0, 9], [1, 4, 0, 35, 2, 1, 8], [0, 6, 2, 30, 1, 0, 7]])
+    rowptr = E._excl_cumsum(lens.reshape(-1))
+    v = E.VirtualRows(rowptr, C, n, target=10)
+    tot = lens.sum(0)
+    parts = torch.clamp((tot + 9) // 10, min=1)
+    assert v.n_vrows == int(parts.sum()) and v.item.numel() == v.n_vrows + 1 and v.slot.numel() == v.n_vrows
+    assert v.item[-1] == n and v.part[-1] == 0 and v.nparts[-1] == 1                     # the sentinel: the end of a block's lists
+    for j in range(n):
+        rows = (v.item[:-1] == j).nonzero().flatten()
+        assert rows.numel() == int(parts[j]) and v.part[rows].tolist() == list(range(int(parts[j])))
+        assert (v.nparts[rows] == int(parts[j])).all() and (rows[1:] - rows[:-1] == 1).all()   # consecutive virtual rows
+        if parts[j] == 1:
+            assert v.slot[rows].tolist() == [-1]
+    cut = (parts > 1).nonzero().flatten()
+    assert v.long_rows.tolist() == cut.tolist() and v.n_long == cut.numel() and v.n_slab == int(parts[cut].sum())
+    for i, j in enumerate(cut.tolist()):
+        rows = (v.item[:-1] == j).nonzero().flatten()
+        b, e = int(v.long_slab_beg[i]), int(v.long_slab_beg[i + 1])
+        assert v.slot[rows].tolist() == list(range(b, e))
+    # the default target: 1.5 x the mean entries per row - ordinary rows stay whole
+    d = E.VirtualRows(rowptr, C, n)
+    assert d.target == int(1.5 * float(tot.double().mean())) + 1 and d.max_parts == int(-(-int(tot.max()) // d.target))
+    # in block t part p of P takes [b + p L / P, b + (p + 1) L / P): the parts tile the list exactly (the kernel's arithmetic)
+    L = 37
+    for P in (1, 2, 5, 11, 40):
+        cuts = [p * L // P for p in range(P + 1)]
+        assert cuts[0] == 0 and cuts[-1] == L and all(a <= b for a, b in zip(cuts, cuts[1:]))
