@@ -261,6 +261,23 @@ int tmf_wmrb_scores5_bf16(const int32_t* ids, const int32_t* outs, const int64_t
                           int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
                           int wgs_per_launch, const int32_t* wstart, int32_t n_windows, int lag, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* Flat streams on the slice-major grid (round 5; speed only - the same sp / p as tmf_wmrb_scores3 up to the order of the fp32 sum
+ * inside a dot product, exact on dyadic data): one workgroup per CHUNK = (item slice, group of tmf_wmrb_scores6_users_per_group()
+ * consecutive users); the group's rows are held in LDS and the chunk's entries are one contiguous piece of
+ *   ids [E8]   (user - first user of the group) << 24 | item      outs [E8]   as for tmf_wmrb_scores5
+ *   chunk_ptr [n_slices * n_groups + 1]   first entry of chunk slice * n_groups + group (every chunk padded to a multiple of 8)
+ * - interactions first, then negatives, each by user and item - so a (user, slice) visit costs no offsets, no row of U and no
+ * dependent round trip of its own.  The slices only order the stream and the grid (the kernel never sees their bounds): any
+ * partition of the item ids into n_slices ascending ranges will do; ~4 MB of V rows each keeps a slice in the XCD L2s.
+ * Same limits as tmf_wmrb_scores5: rows of 32 lanes, n_items < 2^24, V below 4 GB (tmf_wmrb_scores6_supported). */
+int tmf_wmrb_scores6_users_per_group(void);
+int tmf_wmrb_scores6_supported(int n_components, int bf16, int64_t n_items);
+int tmf_wmrb_scores6_f32(const int32_t* ids, const int32_t* outs, const int64_t* chunk_ptr, int64_t n_groups, int32_t n_slices,
+                         int64_t n_users, int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
+                         void* stream);
+int tmf_wmrb_scores6_bf16(const int32_t* ids, const int32_t* outs, const int64_t* chunk_ptr, int64_t n_groups, int32_t n_slices,
+                          int64_t n_users, int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
+                          void* stream);
 int tmf_wmrb_hinge2(const int64_t* rowptr, const float* val, const float* p, const float* sp, int32_t n_users,
                     int32_t n_samples, float c, float* delta, float* D, float* loss_part, void* stream);
 /* The same with the order in which the waves take the users (a permutation of 0 .. n_users - 1, or NULL = 0, 1, 2 ...): a user

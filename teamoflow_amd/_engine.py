@@ -312,6 +312,7 @@ def rows4_wanted(n_components, dtype=torch.float32, plan=None, R=None, n_users=N
     return blocks_wanted > 2 * blocks_slab_allows
 
 
+ROWS5_TARGET_OVER_MEDIAN = 1.15
 ROWS5_BLOCK_BYTES = 4 << 20   # user blocks of the row-stationary item pass (config-5 shard: 160 blocks of 4 MB 80.6 ms, 305 blocks 86.5)
 
 
@@ -326,16 +327,20 @@ def rows5_user_chunks(n_users, n_components, dtype=torch.float32):
 
 class VirtualRows:
     """Work units of tmf_wsum_rows5 (include/tmf.h): output row i with cnt_i list entries (all user blocks together) is cut into
-    P_i = ceil(cnt_i / target) parts, target = 1.5 x the mean (TMF_ROWS5_TARGET overrides): the ordinary rows stay whole, the
-    popular ones become parts of about the mean size, and a lane group's K consecutive virtual rows carry about K x mean entries
+    P_i = ceil(cnt_i / target) parts, target = 1.15 x the median, at least the mean (TMF_ROWS5_TARGET overrides): the ordinary rows
+    stay whole, the popular ones become parts of about the bulk's size, and a lane group's K consecutive virtual rows carry about K x mean entries
     whatever the popularity of its items.  Cut rows get consecutive slab slots (part order) and are finished by tmf_combine_rows."""
 
     def __init__(self, rowptr_e, n_blocks, n_rows, target=None):
         dev = rowptr_e.device
         lens = (rowptr_e[1:] - rowptr_e[:-1]).view(n_blocks, n_rows).sum(0)                       # entries of every output row
         mean = float(lens.to(torch.float64).mean()) if n_rows else 0.0
+        median = float(lens.to(torch.float64).median()) if n_rows else 0.0
         env = os.environ.get('TMF_ROWS5_TARGET')
-        self.target = int(env) if env else (int(target) if target else max(1, int(1.5 * mean) + 1))
+        # just above the bulk of the rows: the ordinary rows stay whole (a cut row costs a slab slot and a second pass over it), whatever
+        # lies above is cut to about the bulk's size.  Config-5 shard (median 1,300, mean 1,405 entries per item), item pass ms by
+        # target: 500: 103   700: 96   1000: 95   1200: 100 (every row cut in two)   1500: 81   2100: 93   4000: 170
+        self.target = int(env) if env else (int(target) if target else max(1, int(max(ROWS5_TARGET_OVER_MEDIAN * median, mean)) + 1))
         parts = torch.clamp((lens + (self.target - 1)) // self.target, min=1)
         first = _excl_cumsum(parts)                                                               # first virtual row of every row
         nv = int(first[-1])
@@ -518,6 +523,91 @@ def wmrb_plan_for(plan, R, n_components, dtype=torch.float32, n_items=None):
     return WmrbPlan(plan, R, user_chunks=C, item_slices=ns, n_components=n_components, sliced=sliced, rows4=rows4)
 
 
+def scores6_wanted(plan, wplan, n_components, dtype=torch.float32):
+    """Whether the sliced user pass computes its scores with flat streams on the slice-major grid (tmf_wmrb_scores6, Scores6Plan)
+    instead of per-(user, slice) visits (tmf_wmrb_scores3).  TMF_SCORES6 = 1 | 0 forces the choice; see SCORES6_MAX_VISIT for the
+    default.  Needs rows of 32 lanes, fewer than 2^24 items, a table below 4 GB and int32 places (m S, nnz < 2^31)."""
+    env = os.environ.get('TMF_SCORES6')
+    if env == '0' or wplan is None or not wplan.sliced or not plan.col_u.is_cuda or os.environ.get('TMF_SCORES5') == '1':
+        return False
+    m, S = wplan.R.shape
+    if m * S >= 2 ** 31 or plan.nnz >= 2 ** 31:
+        return False
+    if not _lib.load_library().tmf_wmrb_scores6_supported(int(n_components), int(dtype is torch.bfloat16), int(plan.n_items)):
+        return False
+    if env == '1':
+        return True
+    row_bytes = _lib.padded_ld(n_components, dtype) * (2 if dtype is torch.bfloat16 else 4)
+    visit = (S + plan.nnz / max(m, 1)) * min(1.0, SCORES6_SLICE_BYTES / max(plan.n_items * row_bytes, 1))
+    return SCORES6_DEFAULT and visit <= SCORES6_MAX_VISIT
+
+
+SCORES6_SLICE_BYTES = 4 << 20   # slices of the flat-stream scores kernel: ~4 MB of V rows, whatever the slice count of the other kernels
+SCORES6_MAX_VISIT = 24          # rows of a (user, 4 MB slice) visit up to which visits are too short for scores3 (config-5 shard: 9; C4: 86)
+SCORES6_DEFAULT = False         # set by measurement (profiles/r05_scores6.txt)
+
+
+class Scores6Plan:
+    """Entry stream of tmf_wmrb_scores6 (include/tmf.h), built once per fit from the sliced plan: every (user, item) pair whose
+    score the epoch needs - interaction k of the CSR (score -> p[k]) and negative (u, pos) of the item-sorted table (score ->
+    sp[u, pos]) - keyed by chunk = slice * n_groups + user group and put in that order by ONE stable radix sort: inside a chunk
+    the interactions come first, then the negatives, each by user and item (so the scores of a user's visit are neighbours in the
+    stream AND in sp / p).  Every chunk is padded to whole steps of 8 entries with its last id and the PAD place."""
+
+    PAD = -2 ** 31
+
+    def __init__(self, plan, wplan, n_components, dtype=torch.float32, slice_bytes=None):
+        lib = _lib.get()
+        dev = plan.col_u.device
+        self.key = (int(n_components), dtype)
+        UG = int(lib.tmf_wmrb_scores6_users_per_group())
+        m, S = wplan.R.shape
+        nnz, n = plan.nnz, plan.n_items
+        E = nnz + m * S
+        self.n_groups = ng = -(-m // UG)
+        row_bytes = _lib.padded_ld(n_components, dtype) * (2 if dtype is torch.bfloat16 else 4)
+        slice_bytes = int(os.environ.get('TMF_S6_SLICE_BYTES', slice_bytes or SCORES6_SLICE_BYTES))
+        ns = int(min(max(1, -(-n * row_bytes // slice_bytes)), max(1, (2 ** 31 - 1) // max(ng, 1))))
+        width = -(-n // ns)
+        self.n_slices = ns = -(-n // width)
+        i32 = torch.int32
+        uo = plan.user_of                                                  # int32 [nnz]
+        rows = torch.arange(m, device=dev, dtype=i32)
+        keys = torch.empty(E, dtype=i32, device=dev)
+        keys[:nnz] = (plan.col_u // width) * ng + uo // UG
+        keys[nnz:].view(m, S).copy_((wplan.R // width) * ng + (rows // UG)[:, None])
+        perm, rowptr = stable_order(keys, ns * ng)
+        del keys
+        packed = torch.empty(E, dtype=i32, device=dev)
+        packed[:nnz] = ((uo % UG) << 24) | plan.col_u
+        packed[nnz:].view(m, S).copy_(((rows % UG) << 24)[:, None] | wplan.R)
+        ids_sorted = packed[perm]
+        del packed
+        outs = torch.empty(E, dtype=i32, device=dev)
+        outs[:nnz] = -1 - torch.arange(nnz, device=dev, dtype=i32)         # ~k: the score of interaction k goes to p[k]
+        outs[nnz:] = torch.arange(m * S, device=dev, dtype=i32)            # u * S + pos: to sp[u, pos]
+        outs_sorted = outs[perm]
+        del outs, perm
+        cnt = rowptr[1:] - rowptr[:-1]
+        ptr8 = _excl_cumsum((cnt + 7) // 8 * 8)
+        E8 = int(ptr8[-1])
+        self.ids = torch.empty(E8 + 8, dtype=i32, device=dev)
+        self.outs = torch.full((E8 + 8,), self.PAD, dtype=i32, device=dev)
+        self.ids[E8:] = 0
+        step = 1 << 27
+        for q0 in range(0, E8, step):
+            q = torch.arange(q0, min(q0 + step, E8), device=dev, dtype=torch.int64)
+            ch = torch.searchsorted(ptr8, q, right=True) - 1
+            r = q - ptr8[ch]
+            c = cnt[ch]
+            src = rowptr[ch] + torch.minimum(r, c - 1)
+            self.ids[q0:q0 + q.numel()] = ids_sorted[src]
+            self.outs[q0:q0 + q.numel()] = torch.where(r < c, outs_sorted[src], torch.full_like(src, self.PAD).to(i32))
+            del q, ch, r, c, src
+        self.chunk_ptr = ptr8
+        self.n_entries, self.n_padded = E, E8
+
+
 def scores5_wanted(plan, wplan, n_components, dtype=torch.float32):
     """Whether the sliced user pass computes its scores with the row-stationary kernel (tmf_wmrb_scores5: workgroups own 256
     users, keep their rows in LDS and walk one flat stream of (user, item) pairs ordered by item) instead of tmf_wmrb_scores3.
@@ -659,6 +749,12 @@ class TrainState:
             else:
                 self.part_layers, self.gradu_launches = 1, 1           # a launch per slice
             need.update(sp=m * S, pk=max(plan.nnz, 1), part=self.part_layers * max(m, 1) * self.ld)
+            wplan.s6 = getattr(wplan, 's6', None)
+            if scores6_wanted(plan, wplan, self.r, dtype):
+                if wplan.s6 is None or wplan.s6.key != (self.r, dtype):
+                    wplan.s6 = Scores6Plan(plan, wplan, self.r, dtype)
+            else:
+                wplan.s6 = None
             if wplan.seg_e is not None and scores5_wanted(plan, wplan, self.r, dtype):
                 if getattr(wplan, 's5', None) is None or wplan.s5.key != (self.r, dtype):
                     wplan.s5 = Scores5Plan(plan, wplan, self.r, dtype)
@@ -786,8 +882,13 @@ def _wmrb_user_pass_sliced(lib, st, adam, c, prof=None, user_epi=_lib.EPI_ADAM, 
         _lib.check(rc_fn(), lib)
         if prof:
             prof.stop(name)
-    s5 = getattr(w, 's5', None)
-    if s5 is not None:
+    s5, s6 = getattr(w, 's5', None), getattr(w, 's6', None)
+    if s6 is not None:
+        # flat streams on the slice-major grid: one workgroup per (slice, group of 32 users) chunk, the group's rows in LDS
+        timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores6' + st.sfx)(
+            _lib.ptr(s6.ids), _lib.ptr(s6.outs), _lib.ptr(s6.chunk_ptr), s6.n_groups, i32(s6.n_slices), m, p.n_items, _lib.ptr(st.U),
+            _lib.ptr(st.V), _lib.ptr(st.sp), _lib.ptr(st.pk), r, s))
+    elif s5 is not None:
         # row-stationary scores: workgroups own 256 users (rows in LDS) and walk one flat stream of (user, item) pairs
         timed('wmrb_scores', lambda: getattr(lib, 'tmf_wmrb_scores5' + st.sfx)(
             _lib.ptr(s5.ids), _lib.ptr(s5.outs), _lib.ptr(s5.wg_ptr), s5.n_wg, m, p.n_items, _lib.ptr(st.U), _lib.ptr(st.V),

@@ -77,6 +77,9 @@ _BASE_SIGNATURES = {
     'tmf_wmrb_user_pass_f32': (_I, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, Adam, _P]),
     'tmf_wmrb_user_pass_fits': (_I, [_I32, _I]),
     'tmf_wmrb_scores3_f32': (_I, [_SL, _P, _P, _P, _P, _I, _P]),
+    'tmf_wmrb_scores6_users_per_group': (_I, []),
+    'tmf_wmrb_scores6_supported': (_I, [_I, _I, _L]),
+    'tmf_wmrb_scores6_f32': (_I, [_P, _P, _P, _L, _I32, _L, _L, _P, _P, _P, _P, _I, _P]),
     'tmf_wmrb_scores5_users_per_workgroup': (_I, []),
     'tmf_wmrb_scores5_supported': (_I, [_I, _I, _L]),
     'tmf_wmrb_scores5_workspace_bytes': (_SZ, [_L, _I32, _I]),
@@ -114,7 +117,7 @@ _BASE_SIGNATURES = {
 }
 
 SIGNATURES.update(_BASE_SIGNATURES)
-for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_scores5', 'tmf_wmrb_gradu3', 'tmf_wmrb_gradu4', 'tmf_wmrb_finish'):
+for _name in ('tmf_wmrb_scores3', 'tmf_wmrb_scores5', 'tmf_wmrb_scores6', 'tmf_wmrb_gradu3', 'tmf_wmrb_gradu4', 'tmf_wmrb_finish'):
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name + '_f32']
 
 _lib = None

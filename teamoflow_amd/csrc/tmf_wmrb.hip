@@ -1309,6 +1309,161 @@ __global__ __launch_bounds__(64 * (kS5Waves + 1)) void k_wmrb_scores5(const int3
 
 }  // namespace tmf
 
+// ---------------------------------------------------------------------------------------------
+// Flat streams on the slice-major grid ("scores6", round 5).  k_wmrb_scores3 pays for every (user, slice)
+// visit with three dependent round trips - offsets -> ids -> rows - and at the config-5 shard a visit is 9 rows at 4 MB slices:
+// with 128 slices it runs 69.5 ms against 59.5 with 64 although its fabric traffic falls from 437 to 256 GB
+// (profiles/r05_c5_slices.txt).  Here a workgroup takes one (slice, group of kS6Users users) CHUNK: the group's rows go to LDS
+// once (as in scores5), and the chunk's entries - interactions, then negatives, each by user and item - are ONE contiguous piece
+// of a stream prepared once per fit (_engine.Scores6Plan): packed (local user << 24 | item) ids and the place every score goes to.
+// One read of the chunk's bounds, then ids and rows: no per-user offsets, no per-visit row of U.  Inside a chunk the entries of a
+// user are consecutive, so the eight scores of a step mostly leave as one 32-byte piece of sp / p.
+// The grid is scores3's: slice-major, every resident workgroup gathers from the same ~4 MB slice of V - no pacing, no rendezvous.
+// Scores agree with k_wmrb_scores3 to rounding (the summation tree of scores5), exactly on dyadic data.
+// ---------------------------------------------------------------------------------------------
+namespace tmf {
+#ifndef TMF_S6_USERS
+#define TMF_S6_USERS 32
+#endif
+#ifndef TMF_S6_WAVES
+#define TMF_S6_WAVES 2
+#endif
+constexpr int kS6Users = TMF_S6_USERS;    // users per chunk (their rows: 16 KB of LDS at 512-byte rows); at most 256 (8-bit local user)
+constexpr int kS6Waves = TMF_S6_WAVES;    // 4 lane groups: a chunk of ~290 entries is ~9 steps of 8 for each
+
+template <int NV, typename T>
+__global__ __launch_bounds__(64 * kS6Waves) void k_wmrb_scores6(const int32_t* __restrict__ ids, const int32_t* __restrict__ outs,
+                                                                const int64_t* __restrict__ chunk_ptr, int64_t chunk0, int64_t n_groups,
+                                                                int64_t n_users, const T* __restrict__ U, const T* __restrict__ V,
+                                                                float* __restrict__ sp, float* __restrict__ p) {
+    constexpr int G = 32, NGB = 2 * kS6Waves;
+    constexpr uint32_t RB = RowBytes<G, NV, T>::value;
+    __shared__ __attribute__((aligned(16))) char smem_raw[kS6Users * RB];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane & (G - 1), gid = tid / G;
+    const int64_t chunk = chunk0 + blockIdx.x;            // = slice * n_groups + group
+    const int64_t beg = chunk_ptr[chunk], end = chunk_ptr[chunk + 1];   // multiples of 8 (padded)
+    if (beg == end) return;                                // no entry of this group in this slice (whole workgroup)
+    const int64_t ubeg = (chunk % n_groups) * kS6Users;
+    const int nu = (int)((n_users - ubeg < kS6Users) ? n_users - ubeg : kS6Users);
+    {
+        const tmf_f4* src = reinterpret_cast<const tmf_f4*>(reinterpret_cast<const char*>(U) + ubeg * (int64_t)RB);
+        tmf_f4* dst = reinterpret_cast<tmf_f4*>(smem_raw);
+        for (int i = tid; i < nu * (int)(RB / 16); i += 64 * kS6Waves) dst[i] = __builtin_nontemporal_load(src + i);
+    }
+    __syncthreads();
+    const int steps = (int)((end - beg) >> 3);
+    const uint32_t loff = 16u * (uint32_t)g;
+    const int my_entry = Reduce8x32::entry_of_lane(lane);
+    const bool owner = Reduce8x32::owner(lane);
+    const int4* id4 = reinterpret_cast<const int4*>(ids + beg);   // 32-byte aligned steps
+    const int32_t* out8 = outs + beg + my_entry;
+    // step i of this lane group is gid + NGB i; the wave runs as many rounds as its first group has steps (the second has as many
+    // or one fewer: beyond its last step a group repeats it and stores nothing), so every load below is unconditional
+    const int mine = steps > gid ? (steps - gid + NGB - 1) / NGB : 0;
+    const int rounds = __builtin_amdgcn_readfirstlane(mine);
+    if (rounds == 0) return;
+    const int last = mine > 0 ? gid + NGB * (mine - 1) : 0;
+    struct Ids {
+        int4 a, b;
+        int o;
+    };
+    auto fetch = [&](int i) {
+        const int st = gid + NGB * i;
+        const int sc = st <= last ? st : last;
+        Ids r{id4[2 * sc], id4[2 * sc + 1], out8[8 * sc]};
+        if (i >= mine) r.o = kS5Pad;
+        return r;
+    };
+    auto gather = [&](Raw<NV, T> (&y)[8], const Ids& d) {
+        const int idv[8] = {d.a.x, d.a.y, d.a.z, d.a.w, d.b.x, d.b.y, d.b.z, d.b.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) load_raw32<G, NV>(y[t], V, (uint32_t)idv[t] & 0xffffffu, loff);
+    };
+    auto finish = [&](const Raw<NV, T> (&y)[8], const Ids& d) {
+        const int idv[8] = {d.a.x, d.a.y, d.a.z, d.a.w, d.b.x, d.b.y, d.b.z, d.b.w};
+        float pr[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            Raw<NV, T> x;   // the entry's user row, from LDS
+            const char* xr = smem_raw + ((uint32_t)idv[t] >> 24) * RB + loff;
+            if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) x.v[v] = *reinterpret_cast<const float4*>(xr + 16 * G * v);
+            } else {
+#pragma unroll
+                for (int pv = 0; pv < NV / 2; ++pv) x.v[pv] = *reinterpret_cast<const bf16x8*>(xr + 16 * G * pv);
+            }
+            pr[t] = dot_raw<NV>(x, y[t]);
+        }
+        const float sc = Reduce8x32::run(pr, lane);
+        if (owner && d.o != kS5Pad) __builtin_nontemporal_store(sc, d.o >= 0 ? sp + d.o : p + ~d.o);
+    };
+    // two rounds in flight per lane group, the ids of round i + 2 asked for BEFORE the rows of round i + 1 (as in scores5)
+    Raw<NV, T> yA[8], yB[8];
+    Ids A = fetch(0);
+    Ids B = fetch(1);
+    gather(yA, A);
+    for (int i = 0; i < rounds; i += 2) {
+        Ids C = fetch(i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(yB, B);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(yA, A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 >= rounds) break;
+        Ids Dn = fetch(i + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(yA, C);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(yB, B);
+        __builtin_amdgcn_sched_barrier(0);
+        A = C;
+        B = Dn;
+    }
+}
+
+}  // namespace tmf
+
+static bool s6_supported(int n_components, int bf16, int64_t n_items) {
+    const tmf::RowGeom geom = bf16 ? tmf::row_geom_bf16(n_components) : tmf::row_geom(n_components);
+    const int64_t row_bytes = (int64_t)geom.ld * (bf16 ? 2 : 4);
+    return geom.G == 32 && n_items > 0 && n_items < (1 << 24) && n_items * row_bytes < ((int64_t)1 << 32);
+}
+
+template <typename T>
+static int wmrb_scores6_impl(const int32_t* ids, const int32_t* outs, const int64_t* chunk_ptr, int64_t n_groups, int32_t n_slices,
+                             int64_t n_users, int64_t n_items, const void* U, const void* V, float* sp, float* p, int n_components,
+                             void* stream) {
+    if (n_users == 0 || n_slices == 0) return TMF_OK;
+    const RowGeom geom = row_geom_of<T>(n_components);
+    TMF_REQUIRE(ids && outs && chunk_ptr && U && V && sp && p, "wmrb_scores6: null pointer");
+    TMF_REQUIRE(n_groups == (n_users + kS6Users - 1) / kS6Users && n_slices > 0, "wmrb_scores6: %lld groups for %lld users (%d per group), %d slices",
+                (long long)n_groups, (long long)n_users, kS6Users, n_slices);
+    if (!s6_supported(n_components, std::is_same<T, __bf16>::value, n_items)) {
+        set_error("wmrb_scores6: needs rows of 32 lanes (fp32 65..128 / bf16 129..256 components) and fewer than 2^24 items in a table "
+                  "below 4 GB (got %d components, %lld items)", n_components, (long long)n_items);
+        return TMF_E_UNSUPPORTED;
+    }
+    // whole slices per launch, fewer than 2^32 work-items each
+    const int64_t per_slice = n_groups * 64 * kS6Waves;
+    const int max_slices = (int)((((int64_t)1 << 32) - 1) / per_slice);
+    TMF_REQUIRE(max_slices >= 1, "wmrb_scores6: %lld user groups exceed one launch", (long long)n_groups);
+    for (int s0 = 0; s0 < n_slices; s0 += max_slices) {
+        const int nsl = (n_slices - s0 < max_slices) ? n_slices - s0 : max_slices;
+        const unsigned blocks = (unsigned)(n_groups * nsl);
+#define CALL(G_, NV_)                                                                                                       \
+    {                                                                                                                       \
+        if constexpr (G_ == 32) {                                                                                           \
+            hipLaunchKernelGGL((k_wmrb_scores6<NV_, T>), dim3(blocks), dim3(64 * kS6Waves), 0, (hipStream_t)stream, ids, outs, \
+                               chunk_ptr, (int64_t)s0 * n_groups, n_groups, n_users, (const T*)U, (const T*)V, sp, p);      \
+        }                                                                                                                   \
+    }
+        TMF_DISPATCH(T, geom, CALL);
+#undef CALL
+    }
+    return check_launch("tmf_wmrb_scores6");
+}
+
 static int s5_launches(int64_t n_wg, int wgs_per_launch) { return (int)((n_wg + wgs_per_launch - 1) / wgs_per_launch); }
 static int s5_wgs_per_launch(int wgs_per_launch) {
     if (wgs_per_launch > 0) return wgs_per_launch;
@@ -1400,6 +1555,11 @@ static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users
         return wmrb_scores5_impl<T_>(ids, outs, wg_ptr, n_wg, n_users, n_items, U, V, sp, p, n_components, wgs_per_launch, \
                                      wstart, n_windows, lag, workspace, workspace_bytes, stream);                         \
     }                                                                                                                     \
+    extern "C" int tmf_wmrb_scores6_##SFX(const int32_t* ids, const int32_t* outs, const int64_t* chunk_ptr, int64_t n_groups, \
+                                          int32_t n_slices, int64_t n_users, int64_t n_items, const void* U, const void* V, \
+                                          float* sp, float* p, int n_components, void* stream) {                          \
+        return wmrb_scores6_impl<T_>(ids, outs, chunk_ptr, n_groups, n_slices, n_users, n_items, U, V, sp, p, n_components, stream); \
+    }                                                                                                                     \
     extern "C" int tmf_wmrb_gradu3_##SFX(const tmf_slice_lists* lists, const float* D, const float* delta,                \
                                          const void* V, float* part, int per_slice_launches, int n_components,            \
                                          void* stream) {                                                                  \
@@ -1419,6 +1579,8 @@ static int wmrb_finish_impl(const float* part, int32_t n_slices, int32_t n_users
 TMF_SLICED_ENTRY_POINTS(f32, float)
 TMF_SLICED_ENTRY_POINTS(bf16, __bf16)
 
+extern "C" int tmf_wmrb_scores6_users_per_group(void) { return tmf::kS6Users; }
+extern "C" int tmf_wmrb_scores6_supported(int n_components, int bf16, int64_t n_items) { return s6_supported(n_components, bf16, n_items); }
 extern "C" int tmf_wmrb_scores5_users_per_workgroup(void) { return tmf::kS5Users; }
 extern "C" size_t tmf_wmrb_scores5_workspace_bytes(int64_t n_wg, int32_t n_windows, int wgs_per_launch) {
     if (n_wg <= 0 || n_windows <= 1) return 0;

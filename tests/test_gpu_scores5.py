@@ -120,7 +120,7 @@ def test_scores5_is_opt_in_only(eng, monkeypatch):
                                           (1_000_000, 64, torch.float32, False), (20_000_000, 128, torch.float32, False)):
         plan, w = P(), P()
         plan.n_items, plan.nnz, plan.n_users, plan.col_u = n_items, 100 * 1000, 1000, torch.zeros(1, device='cuda')
-        w.sliced, w.S = True, 1024
+        w.sliced, w.S, w.R = True, 1024, torch.zeros(1000, 1024)
         monkeypatch.delenv('TMF_SCORES5', raising=False)
         assert not eng.scores5_wanted(plan, w, r, dtype)
         monkeypatch.setenv('TMF_SCORES5', '1')

@@ -289,9 +289,10 @@ def test_virtual_rows_of_the_balanced_item_pass():
         rows = (v.item[:-1] == j).nonzero().flatten()
         b, e = int(v.long_slab_beg[i]), int(v.long_slab_beg[i + 1])
         assert v.slot[rows].tolist() == list(range(b, e))
-    # the default target: 1.5 x the mean entries per row - ordinary rows stay whole
+    # the default target: just above the bulk (1.15 x the median, at least the mean) - ordinary rows stay whole
     d = E.VirtualRows(rowptr, C, n)
-    assert d.target == int(1.5 * float(tot.double().mean())) + 1 and d.max_parts == int(-(-int(tot.max()) // d.target))
+    assert d.target == int(max(1.15 * float(tot.double().median()), float(tot.double().mean()))) + 1
+    assert d.max_parts == int(-(-int(tot.max()) // d.target))
     # in block t part p of P takes [b + p L / P, b + (p + 1) L / P): the parts tile the list exactly (the kernel's arithmetic)
     L = 37
     for P in (1, 2, 5, 11, 40):
