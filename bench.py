@@ -150,7 +150,7 @@ def init_table(rows, r, seed, dev):
 #             (or the cache-sized window the kernel is blocked into) once per sweep when it is cache-resident
 #             (<= 256 MiB Infinity Cache), every gathered row when it is not.
 # ---------------------------------------------------------------------------------------------
-def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, part_layers=None, u_sweeps=1):
+def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, part_layers=None, u_sweeps=1, flat_streams=False):
     row = ld * s          # bytes of one factor row as stored
     row32 = ld * 4        # fp32 partial / gradient rows
     U_tab, V_tab = m * row, n * row
@@ -161,10 +161,14 @@ def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, p
         layers = ns if part_layers is None else part_layers
         # gradU partial rows: one fp32 layer per slice written once, or (memory-light) ONE layer read-modified-written per slice
         part_wr = ns * m * row32 if layers == ns else (2 * ns - 1) * m * row32
+        # flat_streams (tmf_wmrb_scores6): 8 bytes of stream per entry (packed id + place) instead of 4 bytes of id + the offsets
         k['wmrb_scores'] = dict(rows=m * S + nnz, gather=(m * S + nnz) * row,
-                                hbm=m * S * 4 + off + nnz * 4 + U_tab + (V_tab if v_resident else (m * S + nnz) * row) + m * S * 4 + nnz * 4,
+                                hbm=((m * S + nnz) * 8 if flat_streams else m * S * 4 + off + nnz * 4) + U_tab
+                                + (V_tab if v_resident else (m * S + nnz) * row) + m * S * 4 + nnz * 4,
                                 roof='l2' if v_resident else 'hbm',
-                                what='sampled + interaction scores: V rows gathered from the L2-resident slice, ids staged in LDS')
+                                what=('sampled + interaction scores: one workgroup per (slice, 32 users) chunk of a flat entry stream, the users\' rows '
+                                      'in LDS, V rows gathered from the L2-resident slice' if flat_streams else
+                                      'sampled + interaction scores: V rows gathered from the L2-resident slice, ids staged in LDS'))
         k['wmrb_hinge'] = dict(rows=0, gather=0, hbm=m * S * 4 + 2 * nnz * 4 + m * 8 + m * S * 4 + nnz * 4, roof='issue',
                                what='sort + binary search + scans per user (one wave per user); streams sp / p in, D / delta out')
         k['wmrb_gradu'] = dict(rows=m * S + nnz, gather=(m * S + nnz) * row,
@@ -292,7 +296,7 @@ def roofline_report(models, prof, pmc=None):
 
 
 # kernel symbol prefixes of the per-kernel timer names, for matching the committed PMC profile
-PMC_KERNELS = {'wmrb_scores': 'tmf::k_wmrb_scores3', 'wmrb_hinge': 'tmf::k_wmrb_hinge2', 'wmrb_gradu': 'tmf::k_wmrb_gradu3',
+PMC_KERNELS = {'wmrb_scores': ('tmf::k_wmrb_scores', ''), 'wmrb_hinge': 'tmf::k_wmrb_hinge2', 'wmrb_gradu': 'tmf::k_wmrb_gradu3',
                'wmrb_finish': 'tmf::k_wmrb_finish', 'wmrb_item_pass': ('tmf::k_wsum_', ''), 'wmrb_combine': 'tmf::k_combine_rows',
                'wmrb_user_pass': 'tmf::k_wmrb_user',
                # the two launches per epoch of one kernel, told apart by dispatch order in tools/profile_summary.py
@@ -640,10 +644,10 @@ class Workload:
                 work = w.vrows.n_vrows if w.vrows is not None else self.n
                 return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced, int(w.rowptr_e[-1]),
                                           w.vrows.n_slab if w.vrows is not None else 0, w.user_chunks, getattr(st, 'part_layers', None),
-                                          u_sweeps=max(2, -(-work // st.rows4_per_launch)))
+                                          u_sweeps=max(2, -(-work // st.rows4_per_launch)), flat_streams=getattr(w, 's6', None) is not None)
             return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced,
                                       int(w.rowptr_e[-1]), w.seg_e.n_slab if w.seg_e is not None else 0, w.user_chunks,
-                                      getattr(st, 'part_layers', None))
+                                      getattr(st, 'part_layers', None), flat_streams=getattr(w, 's6', None) is not None)
         return mse_kernel_models(self.m, self.n, self.nnz, st.ld, s)
 
     def describe(self, tag):

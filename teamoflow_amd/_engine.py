@@ -544,7 +544,7 @@ def scores6_wanted(plan, wplan, n_components, dtype=torch.float32):
 
 SCORES6_SLICE_BYTES = 4 << 20   # slices of the flat-stream scores kernel: ~4 MB of V rows, whatever the slice count of the other kernels
 SCORES6_MAX_VISIT = 24          # rows of a (user, 4 MB slice) visit up to which visits are too short for scores3 (config-5 shard: 9; C4: 86)
-SCORES6_DEFAULT = False         # set by measurement (profiles/r05_scores6.txt)
+SCORES6_DEFAULT = True          # config-5 shard: 55.4 ms against 59.5 for scores3, fabric traffic 183 GB against 446 (profiles/r05_c5_shard.txt)
 
 
 class Scores6Plan:
