@@ -509,6 +509,18 @@ class WmrbPlan:
         return out
 
 
+def row_stationary_wanted(n_users, n_items, n_samples, nnz, n_components, dtype=torch.float32, sliced=True):
+    """Whether gradU runs row-stationary (tmf_wmrb_gradu4: lane groups own users, keep their gradient rows in registers and walk
+    all slices; no partial rows, no finish kernel).  TMF_ROW_STATIONARY = 1 | 0 forces it; default: where the visits are short
+    (short_visits) and the kernel exists for the geometry."""
+    env = os.environ.get('TMF_ROW_STATIONARY')
+    if env == '0' or not sliced:
+        return False
+    if not _lib.load_library().tmf_wmrb_gradu4_supported(int(n_components), int(dtype is torch.bfloat16)):
+        return False
+    return env == '1' or short_visits(n_users, n_items, n_samples, nnz, n_components, dtype)
+
+
 def wmrb_plan_for(plan, R, n_components, dtype=torch.float32, n_items=None):
     """The WmrbPlan a fit builds for (plan, R): the user-pass form (choose_wmrb_user_pass), the item-pass form (rows4_wanted) and the
     user blocks that go with it - ONE place for MatrixFactorization._fit_sparse, dist.fit_data_parallel and bench.py.
@@ -518,6 +530,11 @@ def wmrb_plan_for(plan, R, n_components, dtype=torch.float32, n_items=None):
     bf16 = dtype is torch.bfloat16
     ld_store = _lib.padded_ld(n_components, dtype)
     ns, sliced = choose_wmrb_user_pass(m, n, ld_store, int(R.shape[1]), plan.n_pos, n_components, elem_size=2 if bf16 else 4)
+    # short visits (config-5 shard): the row-stationary gradU with its own slice size, unless the environment decides
+    # (TMF_ROW_STATIONARY = 0 | 1, TMF_ITEM_SLICES)
+    rs = row_stationary_wanted(m, n, int(R.shape[1]), plan.nnz, n_components, dtype, sliced)
+    if rs and not os.environ.get('TMF_ITEM_SLICES'):
+        ns = int(max(1, -(-n * ld_store * (2 if bf16 else 4) // GRADU4_SLICE_BYTES)))
     rows4 = rows4_wanted(n_components, dtype, plan, R)
     C = rows5_user_chunks(m, n_components, dtype) if rows4 else default_user_chunks(m, _lib.padded_ld(n_components), n_items=plan.n_items)
     return WmrbPlan(plan, R, user_chunks=C, item_slices=ns, n_components=n_components, sliced=sliced, rows4=rows4)
@@ -537,12 +554,26 @@ def scores6_wanted(plan, wplan, n_components, dtype=torch.float32):
         return False
     if env == '1':
         return True
+    return SCORES6_DEFAULT and short_visits(m, plan.n_items, S, plan.nnz, n_components, dtype)
+
+
+def short_visits(n_users, n_items, n_samples, nnz, n_components, dtype=torch.float32):
+    """Whether a (user, ~4 MB slice of V) visit of the sliced user pass is only a handful of rows - S x slice bytes / table bytes
+    (+ the user's interactions in the slice): 9 at the config-5 shard (1M items x 512 bytes), 88 at C4.  Short visits are what
+    tmf_wmrb_scores3 / gradu3 pay their per-visit round trips, their row of U and their partial row for; such shapes take the flat
+    streams (tmf_wmrb_scores6) and the row-stationary gradU (tmf_wmrb_gradu4) instead."""
     row_bytes = _lib.padded_ld(n_components, dtype) * (2 if dtype is torch.bfloat16 else 4)
-    visit = (S + plan.nnz / max(m, 1)) * min(1.0, SCORES6_SLICE_BYTES / max(plan.n_items * row_bytes, 1))
-    return SCORES6_DEFAULT and visit <= SCORES6_MAX_VISIT
+    table = n_items * row_bytes
+    if table < 8 * VISIT_SLICE_BYTES:   # short because the catalog is cut fine, not because a user has few negatives (tiny S)
+        return False
+    return (n_samples + nnz / max(n_users, 1)) * VISIT_SLICE_BYTES / table <= SCORES6_MAX_VISIT
 
 
-SCORES6_SLICE_BYTES = 4 << 20   # slices of the flat-stream scores kernel: ~4 MB of V rows, whatever the slice count of the other kernels
+SCORES6_SLICE_BYTES = 6 << 20   # slices of the flat-stream scores kernel, whatever the slice count of the other kernels.  Config-5 shard, scores ms
+                                # by slice size: 2 MB 70.3   3 MB 59.6   4 MB 55.4   5 MB 53.9   6 MB 52.9   7 MB 53.8   8 MB 56.9 (scores3, 8 MB: 59.5)
+VISIT_SLICE_BYTES = 4 << 20     # the slice size a visit's length is judged at (short_visits)
+GRADU4_SLICE_BYTES = 3200000    # 3.2 MB slices for the row-stationary gradU: config-5 shard 160 slices 74.8 ms (128: 77.4, 192: 75.8, 256: 82.2;
+                                # gradu3 + finish at 64 slices: 82.3)
 SCORES6_MAX_VISIT = 24          # rows of a (user, 4 MB slice) visit up to which visits are too short for scores3 (config-5 shard: 9; C4: 86)
 SCORES6_DEFAULT = True          # config-5 shard: 55.4 ms against 59.5 for scores3, fabric traffic 183 GB against 446 (profiles/r05_c5_shard.txt)
 
@@ -733,8 +764,7 @@ class TrainState:
         self.row_stationary = False
         if wplan is not None and wplan.sliced:
             m, S = wplan.R.shape
-            self.row_stationary = (os.environ.get('TMF_ROW_STATIONARY') == '1'
-                                   and bool(_lib.load_library().tmf_wmrb_gradu4_supported(self.r, int(dtype is torch.bfloat16))))
+            self.row_stationary = row_stationary_wanted(m, plan.n_items, S, plan.nnz, self.r, dtype)
             self.users_per_launch = int(os.environ.get('TMF_G4_USERS', 32768))
             if self.row_stationary:
                 nb = _lib.load_library().tmf_wmrb_gradu4_workspace_bytes(m, wplan.n_slices, self.users_per_launch)

@@ -52,8 +52,10 @@ def c5():
     assert wplan.user_chunks > 1 and wplan.n_slices > 1
     # this is the shape the balanced row-stationary item pass (tmf_wsum_rows5) is the default for: the popular items are cut
     assert wplan.rows4 and wplan.vrows is not None and wplan.vrows.n_long > 0 and wplan.vrows.max_parts > 50
+    assert wplan.n_slices == 160      # 3.2 MB slices: the row-stationary gradU (tmf_wmrb_gradu4) is the default at this shape, ...
     st = _engine.TrainState(U0.float(), V0.float(), plan, r, wplan, dtype=torch.bfloat16)
     assert torch.equal(st.U[:, :r], U0) and torch.equal(st.V[:, :r], V0)
+    assert st.row_stationary and wplan.s6 is not None and wplan.s6.n_slices == 82     # ... and so are the flat-stream scores (6 MB slices)
     adam = _engine.adam_constants(lr)
     loss = torch.zeros(2, dtype=torch.float64, device=dev)
     _engine.epoch_wmrb(st, adam, n / S, loss[0:1])

@@ -123,3 +123,18 @@ def test_the_item_pass_form_follows_the_shape(eng, monkeypatch):
     monkeypatch.setenv('TMF_ROWS4', '0')
     assert not eng.rows4_wanted(256, bf, n_users=1_250_000, n_items=1_000_000)
     assert eng.rows5_user_chunks(1_250_000, 256, bf) == 153      # 4 MB of bf16 rows per block
+
+
+def test_the_user_pass_forms_follow_the_shape_too(eng, monkeypatch):
+    """Short (user, 4 MB slice) visits - the config-5 shard: 9 rows - take the flat-stream scores kernel and the row-stationary
+    gradU with 3.2 MB slices; C4 (88 rows per visit) and the small configurations keep scores3 / gradu3."""
+    for k in ('TMF_ROW_STATIONARY', 'TMF_SCORES6', 'TMF_SCORES5', 'TMF_ITEM_SLICES'):
+        monkeypatch.delenv(k, raising=False)
+    bf, f32 = torch.bfloat16, torch.float32
+    assert eng.short_visits(1_250_000, 1_000_000, 1024, 125_000_000, 256, bf)
+    assert not eng.short_visits(1_000_000, 100_000, 1024, 100_000_000, 128, f32)
+    assert not eng.short_visits(6040, 3706, 1853, 1_000_209, 64, f32) and not eng.short_visits(50, 100, 5, 200, 128, f32)
+    assert eng.row_stationary_wanted(1_250_000, 1_000_000, 1024, 125_000_000, 256, bf)
+    assert not eng.row_stationary_wanted(1_000_000, 100_000, 1024, 100_000_000, 128, f32)
+    monkeypatch.setenv('TMF_ROW_STATIONARY', '0')
+    assert not eng.row_stationary_wanted(1_250_000, 1_000_000, 1024, 125_000_000, 256, bf)
