@@ -25,6 +25,9 @@
 
 namespace tmf {
 
+#ifndef TMF_HINGE_PRELOAD
+#define TMF_HINGE_PRELOAD 1
+#endif
 constexpr int HK = 256;             // slots of a chunk's sorted threshold array
 constexpr int HCHUNK = HK - 1;      // entries per chunk: at least one +inf slot stays, so rho <= HK - 1
 constexpr int HPAD = HK + HK / 32;  // slot i lives at i + (i >> 5): the search's reads spread over the banks
@@ -111,6 +114,13 @@ __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
 
     float lsum = 0.f;
     bool wrote = false;  // D[u, :] holds this user's values already (later chunks add)
+#if TMF_HINGE_PRELOAD
+    // the first two tiles of sampled scores (all of them up to S = 1024) are asked for NOW, before the chain rowptr -> val / p ->
+    // sort that every chunk starts with: their latency overlaps it instead of following it
+    float xpre[2][HSPL];
+    load_tile(spu, 0, S, lane, xpre[0]);
+    load_tile(spu, 64 * HSPL, S, lane, xpre[1]);
+#endif
     for (int64_t cb = rb; cb < re; cb += HCHUNK) {
         const int len = (int)((re - cb < HCHUNK) ? (re - cb) : HCHUNK);
         // ---- 1. thresholds and sort keys of the chunk (entry i = lane + 64 q) ----
@@ -195,7 +205,16 @@ __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
                 if (tile >= ntiles) break;
                 float x[HSPL];
                 int rho[HSPL];
+#if TMF_HINGE_PRELOAD
+                if (tp == 0) {
+#pragma unroll
+                    for (int j = 0; j < HSPL; ++j) x[j] = xpre[h][j];
+                } else {
+                    load_tile(spu, tile * 64 * HSPL, S, lane, x);
+                }
+#else
                 load_tile(spu, tile * 64 * HSPL, S, lane, x);
+#endif
                 search_tile(L.ts, x, rho, nfin);
 #pragma unroll
                 for (int j = 0; j < HSPL; ++j) {

@@ -310,6 +310,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) TMF_WSUM_OCC void k_wsum_pass_
 // partial sums), so the two forms agree to rounding, not to the bit.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRows4Tile = 64;
+// Rows per lane group (K) and rows in flight (U) of the row-stationary pass for rows of 8 accumulator registers (bf16 r = 256, the
+// config-5 shard), item pass ms at 128 VGPRs / 4 waves per SIMD (profiles/r05_c5_shard.txt): K=8 U=4 81.1 (rounds 3-4)  K=8 U=6 108.6
+// K=8 U=8 129.3 (spills)  K=7 U=5 75.7  K=6 U=4 74.9  K=6 U=5 70.6  K=6 U=6 70.5  K=6 U=7 79.4  K=5 U=6 70.4  K=5 U=8 83.0;
+// 4-wave workgroups at 3 per CU (168 VGPRs): K=8 U=6 82.0, K=10 U=6 81.4.  A (user block, row) run is ~9 entries: 6 + 3 instead of
+// 4 + 4 + 1 dependent trips.  Rows of 4 accumulator registers (fp32 r <= 256) keep K = 15, U = 4 (not re-measured).
+#ifndef TMF_ROWS4_UNROLL
+#define TMF_ROWS4_UNROLL 6
+#endif
+constexpr int kRows4Unroll2 = TMF_ROWS4_UNROLL, kRows4Unroll1 = 4;   // rows in flight per lane group: NV >= 2 / NV = 1
+#ifndef TMF_ROWS4_K2
+#define TMF_ROWS4_K2 6
+#endif
+#ifndef TMF_ROWS4_WAVES
+#define TMF_ROWS4_WAVES 8
+#endif
+#ifndef TMF_ROWS4_MINW
+#define TMF_ROWS4_MINW (TMF_ROWS4_WAVES / 2)   // waves per SIMD the register allocation must allow (4: two 8-wave workgroups per CU)
+#endif
+constexpr int kRows4Waves = TMF_ROWS4_WAVES;
+constexpr int kRows4K2 = TMF_ROWS4_K2;           // output rows per lane group when a row takes 8 accumulator registers (NV = 2)
 
 // BALANCED form ("rows5", round 5): the rows a lane group owns are VIRTUAL rows - (output row, part p of P) - listed in (row, part)
 // order, so that a popular item (C4 / config 5: the top item has one list entry per user, the average 1,400) is cut into P parts
@@ -328,13 +348,13 @@ struct VRows {
 };
 
 template <int G, int NV, typename T, int K, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wsum_rows4(
+__global__ __launch_bounds__(64 * WAVES, TMF_ROWS4_MINW) void k_wsum_rows4(
     const int64_t* __restrict__ rowptr, int64_t n_rows, int n_blocks, const int32_t* __restrict__ ent_row,
     const int32_t* __restrict__ ent_w, const float* __restrict__ wbuf, const T* __restrict__ Tab, const T* __restrict__ X_old,
     void* __restrict__ X_out, int epi, tmf_adam adam, int64_t row_begin, int64_t row_end, int* __restrict__ sync, int lag,
     VRows vr) {
     static_assert(K + 1 <= G, "the list boundaries of a block live in one register of the lane group");
-    constexpr int NG = 64 / G, NGB = NG * WAVES;
+    constexpr int NG = 64 / G, NGB = NG * WAVES, U = NV >= 2 ? kRows4Unroll2 : kRows4Unroll1;
     __shared__ int s_ids[NGB][kRows4Tile];
     __shared__ float s_w[NGB][kRows4Tile];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -366,25 +386,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wsum_rows4(
         for (int c0 = r_beg; c0 < r_end; c0 += kRows4Tile) {
             const int cnt = (r_end - c0 < kRows4Tile) ? r_end - c0 : kRows4Tile;
             for (int e = g; e < cnt; e += G) {
+#if TMF_WSUM_VARIANT == 1   // timing only (see k_wsum_pass_pg): no 4-byte weight gather
+                ids[e] = ent_row[c0 + e];
+                ws[e] = __int_as_float(0x3f800000 | (ent_w[c0 + e] & 0xffff));
+#elif TMF_WSUM_VARIANT == 2   // timing only: sixteen L1-resident rows
+                ids[e] = ent_row[c0 + e] & 15;
+                ws[e] = wbuf[ent_w[c0 + e]];
+#elif TMF_WSUM_VARIANT == 3
+                ids[e] = ent_row[c0 + e] & 15;
+                ws[e] = __int_as_float(0x3f800000 | (ent_w[c0 + e] & 0xffff));
+#else
                 ids[e] = ent_row[c0 + e];
                 ws[e] = wbuf[ent_w[c0 + e]];
+#endif
             }
             wave_lds_sync();
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int lo = (b[k] > c0 ? b[k] : c0) - c0;
                 const int hi = ((b[k + 1] < c0 + cnt) ? b[k + 1] : c0 + cnt) - c0;
-                for (int e0 = lo; e0 < hi; e0 += kUnroll) {
-                    Raw<NV, T> raw[kUnroll];
-                    float wc[kUnroll];
+                for (int e0 = lo; e0 < hi; e0 += U) {
+                    Raw<NV, T> raw[U];
+                    float wc[U];
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
+                    for (int u = 0; u < U; ++u) {
                         const int e = e0 + u;
                         wc[u] = (e < hi) ? ws[e] : 0.f;
                         load_raw<G, NV>(raw[u], Tab, ids[(wc[u] != 0.f) ? e : lo], g);   // weight 0: an L1-hot row times 0
                     }
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
+                    for (int u = 0; u < U; ++u) {
                         Frag<NV> y;
                         to_frag<NV>(y, raw[u]);
                         axpy<NV>(acc[k], wc[u], y);
@@ -668,8 +699,8 @@ static int wsum_rows4_impl(const int64_t* rowptr, int32_t n_rows, int32_t n_bloc
         set_error("wsum_rows4: rows of %d lanes are too narrow for the row-stationary form; use tmf_wsum_pass + tmf_combine_rows", geom.G);
         return TMF_E_UNSUPPORTED;
     }
-    constexpr int W4 = 8;
-    const int K4 = geom.NV >= 2 ? 8 : 15;   // rows per lane group: 8 x 8 or 15 x 4 accumulator registers
+    constexpr int W4 = kRows4Waves;
+    const int K4 = geom.NV >= 2 ? kRows4K2 : 15;   // rows per lane group: 6 x 8 or 15 x 4 accumulator registers
     const int64_t per_block = (int64_t)(64 / geom.G) * W4 * K4;
     const int64_t launches = (n_work + rows_per_launch - 1) / rows_per_launch;
     int* sync = nullptr;
@@ -693,12 +724,12 @@ static int wsum_rows4_impl(const int64_t* rowptr, int32_t n_rows, int32_t n_bloc
             if (geom.NV == 1 && geom.G == 16) { CALLK(16, 1, 15); }
             else if (geom.NV == 1 && geom.G == 32) { CALLK(32, 1, 15); }
             else if (geom.NV == 1 && geom.G == 64) { CALLK(64, 1, 15); }
-            else if (geom.NV == 2 && geom.G == 64) { CALLK(64, 2, 8); }
+            else if (geom.NV == 2 && geom.G == 64) { CALLK(64, 2, kRows4K2); }
             else { set_error("wsum_rows4: unsupported n_components"); return TMF_E_UNSUPPORTED; }
         } else {
-            if (geom.NV == 2 && geom.G == 16) { CALLK(16, 2, 8); }
-            else if (geom.NV == 2 && geom.G == 32) { CALLK(32, 2, 8); }
-            else if (geom.NV == 2 && geom.G == 64) { CALLK(64, 2, 8); }
+            if (geom.NV == 2 && geom.G == 16) { CALLK(16, 2, kRows4K2); }
+            else if (geom.NV == 2 && geom.G == 32) { CALLK(32, 2, kRows4K2); }
+            else if (geom.NV == 2 && geom.G == 64) { CALLK(64, 2, kRows4K2); }
             else { set_error("wsum_rows4: unsupported n_components"); return TMF_E_UNSUPPORTED; }
         }
 #undef CALLK
@@ -709,7 +740,7 @@ static int wsum_rows4_impl(const int64_t* rowptr, int32_t n_rows, int32_t n_bloc
 extern "C" int tmf_wsum_rows4_rows_per_group(int n_components, int bf16) {
     const RowGeom geom = bf16 ? row_geom_bf16(n_components) : row_geom(n_components);
     if (geom.ld == 0 || geom.G < 16 || (geom.NV != 1 && geom.NV != 2)) return 0;
-    return (64 / geom.G) * 8 * (geom.NV >= 2 ? 8 : 15);   // rows one 512-thread workgroup owns
+    return (64 / geom.G) * kRows4Waves * (geom.NV >= 2 ? kRows4K2 : 15);   // rows one workgroup owns
 }
 extern "C" size_t tmf_wsum_rows4_workspace_bytes(int32_t n_rows, int32_t n_blocks, int32_t rows_per_launch) {
     return rows_per_launch > 0 ? rendezvous_bytes(((int64_t)n_rows + rows_per_launch - 1) / rows_per_launch, n_blocks) : 0;
