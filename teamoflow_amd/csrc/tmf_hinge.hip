@@ -19,15 +19,17 @@
 //      the cancellation in cnt c1 + sum sp costs nothing), then M_k, the loss, w_k and delta_k in fp32 as before;
 //   5. an exclusive prefix scan of w over the sorted positives gives D[s] += prefix[rho_s].
 // No factor table is touched: p comes from tmf_wmrb_scores3, sum_k delta_k V[j_k] is done by tmf_wmrb_gradu3.
+// Round 5, two attempts to take the sampled scores' load off the critical path (asked for BEFORE the chain rowptr -> val / p -> sort,
+// so that its latency overlaps it), both measured slower and removed (gpurun_out/r05_hinge_ab.txt; C4 / config-5 shard ms):
+//   in registers (16 more: 144 VGPRs, three waves per SIMD)     4.68 -> 5.33      5.7 -> 6.4
+//   by LDS-DMA into 4 KB more LDS per wave, registers capped at 128 (52 bytes of scratch)   4.67 -> 5.17      5.6 -> 6.3
+// The kernel sits exactly on the 128-register border of four waves per SIMD; anything added costs more than the latency it hides.
 #include <math.h>
 
 #include "tmf_common.h"
 
 namespace tmf {
 
-#ifndef TMF_HINGE_PRELOAD
-#define TMF_HINGE_PRELOAD 1
-#endif
 constexpr int HK = 256;             // slots of a chunk's sorted threshold array
 constexpr int HCHUNK = HK - 1;      // entries per chunk: at least one +inf slot stays, so rho <= HK - 1
 constexpr int HPAD = HK + HK / 32;  // slot i lives at i + (i >> 5): the search's reads spread over the banks
@@ -114,13 +116,6 @@ __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
 
     float lsum = 0.f;
     bool wrote = false;  // D[u, :] holds this user's values already (later chunks add)
-#if TMF_HINGE_PRELOAD
-    // the first two tiles of sampled scores (all of them up to S = 1024) are asked for NOW, before the chain rowptr -> val / p ->
-    // sort that every chunk starts with: their latency overlaps it instead of following it
-    float xpre[2][HSPL];
-    load_tile(spu, 0, S, lane, xpre[0]);
-    load_tile(spu, 64 * HSPL, S, lane, xpre[1]);
-#endif
     for (int64_t cb = rb; cb < re; cb += HCHUNK) {
         const int len = (int)((re - cb < HCHUNK) ? (re - cb) : HCHUNK);
         // ---- 1. thresholds and sort keys of the chunk (entry i = lane + 64 q) ----
@@ -205,16 +200,7 @@ __global__ __launch_bounds__(64 * HWAVES) void k_wmrb_hinge2(
                 if (tile >= ntiles) break;
                 float x[HSPL];
                 int rho[HSPL];
-#if TMF_HINGE_PRELOAD
-                if (tp == 0) {
-#pragma unroll
-                    for (int j = 0; j < HSPL; ++j) x[j] = xpre[h][j];
-                } else {
-                    load_tile(spu, tile * 64 * HSPL, S, lane, x);
-                }
-#else
                 load_tile(spu, tile * 64 * HSPL, S, lane, x);
-#endif
                 search_tile(L.ts, x, rho, nfin);
 #pragma unroll
                 for (int j = 0; j < HSPL; ++j) {

@@ -1066,7 +1066,10 @@ static int wmrb_gradu4_impl(const tmf_slice_lists* lists, const float* D, const 
         set_error("wmrb_gradu4: rows of %d lanes are too narrow for the row-stationary form; use tmf_wmrb_gradu3 + tmf_wmrb_finish", geom.G);
         return TMF_E_UNSUPPORTED;
     }
-    constexpr int K4 = 4;
+#ifndef TMF_G4_K
+#define TMF_G4_K 4
+#endif
+    constexpr int K4 = TMF_G4_K;   // users per lane group (A/B builds)
     const int cap = geom.G < 16 ? geom.G : 16;
     const size_t lds = (size_t)(64 / geom.G) * W4 * 2 * K4 * 2 * cap * sizeof(int);
     const int64_t per_block = (int64_t)(64 / geom.G) * W4 * K4;
