@@ -20,7 +20,7 @@
 //   5. an exclusive prefix scan of w over the sorted positives gives D[s] += prefix[rho_s].
 // No factor table is touched: p comes from tmf_wmrb_scores3, sum_k delta_k V[j_k] is done by tmf_wmrb_gradu3.
 // Round 5, two attempts to take the sampled scores' load off the critical path (asked for BEFORE the chain rowptr -> val / p -> sort,
-// so that its latency overlaps it), both measured slower and removed (gpurun_out/r05_hinge_ab.txt; C4 / config-5 shard ms):
+// so that its latency overlaps it), both measured slower and removed (profiles/r05_all_ab_runs_raw.txt; C4 / config-5 shard ms):
 //   in registers (16 more: 144 VGPRs, three waves per SIMD)     4.68 -> 5.33      5.7 -> 6.4
 //   by LDS-DMA into 4 KB more LDS per wave, registers capped at 128 (52 bytes of scratch)   4.67 -> 5.17      5.6 -> 6.3
 // The kernel sits exactly on the 128-register border of four waves per SIMD; anything added costs more than the latency it hides.

@@ -11,6 +11,10 @@ namespace tmf {
 
 constexpr int kWavesPerBlock = 2;   // independent waves, no barrier; 2 per workgroup measured best (C4 item pass 32.1 ms; 4: 32.5, 8: 36.6; MSE epoch 11.1 vs 11.45)
 constexpr int kUnroll = 4;          // list entries a group keeps in flight
+#ifndef TMF_MSE_UNROLL
+#define TMF_MSE_UNROLL 4
+#endif
+constexpr int kMseUnroll = TMF_MSE_UNROLL;   // the same for k_mse_pass (A/B builds)
 constexpr int64_t kMaxBlocks = ((int64_t)1 << 32) / (64 * kWavesPerBlock) - 1;   // workgroups of one launch: < 2^32 work-items
 
 struct SegView {
@@ -51,15 +55,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
     zero<NV>(acc);
     float lsum = 0.f;
 
-    for (int64_t k0 = beg + grp; k0 < end; k0 += (int64_t)NG * kUnroll) {
-        Raw<NV, T> raw[kUnroll];
-        float a[kUnroll];
-        int j[kUnroll];
-        bool ok[kUnroll];
+    for (int64_t k0 = beg + grp; k0 < end; k0 += (int64_t)NG * kMseUnroll) {
+        Raw<NV, T> raw[kMseUnroll];
+        float a[kMseUnroll];
+        int j[kMseUnroll];
+        bool ok[kMseUnroll];
         // ids and values first, unconditionally (index clamped into the segment), so that the four id loads
         // are in flight together instead of one id -> row round trip after the other
 #pragma unroll
-        for (int t = 0; t < kUnroll; ++t) {
+        for (int t = 0; t < kMseUnroll; ++t) {
             const int64_t k = k0 + (int64_t)t * NG;
             ok[t] = k < end;
             const int64_t kc = ok[t] ? k : end - 1;
@@ -67,11 +71,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mse_pass(
             a[t] = val[kc];
         }
 #pragma unroll
-        for (int t = 0; t < kUnroll; ++t) {
+        for (int t = 0; t < kMseUnroll; ++t) {
             load_raw<G, NV>(raw[t], Y_old, j[t], g);  // padded slots re-read the segment's last entry; masked below
         }
 #pragma unroll
-        for (int t = 0; t < kUnroll; ++t) {
+        for (int t = 0; t < kMseUnroll; ++t) {
             Frag<NV> y;
             to_frag<NV>(y, raw[t]);
             const float p = group_allsum<G>(dot_partial<NV>(x, y));
