@@ -166,7 +166,7 @@ def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, p
                                 hbm=((m * S + nnz) * 8 if flat_streams else m * S * 4 + off + nnz * 4) + U_tab
                                 + (V_tab if v_resident else (m * S + nnz) * row) + m * S * 4 + nnz * 4,
                                 roof='l2' if v_resident else 'hbm',
-                                what=('sampled + interaction scores: one workgroup per (slice, 32 users) chunk of a flat entry stream, the users\' rows '
+                                what=('sampled + interaction scores: one workgroup per (slice, 64 users) chunk of a flat entry stream, the users\' rows '
                                       'in LDS, V rows gathered from the L2-resident slice' if flat_streams else
                                       'sampled + interaction scores: V rows gathered from the L2-resident slice, ids staged in LDS'))
         k['wmrb_hinge'] = dict(rows=0, gather=0, hbm=m * S * 4 + 2 * nnz * 4 + m * 8 + m * S * 4 + nnz * 4, roof='issue',

@@ -20,6 +20,10 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kPosChunk = 512;
 constexpr int kUnrollW = 4;
+#ifndef TMF_G4_UNROLL
+#define TMF_G4_UNROLL 4
+#endif
+constexpr int kG4Unroll = TMF_G4_UNROLL;   // rows in flight per lane group of k_wmrb_gradu4 (4 or 8; A/B builds)
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wmrb_gradu4(   // two
                                                           void* __restrict__ U_out, int epi, tmf_adam adam, int64_t user_begin,
                                                           int64_t user_end, int* __restrict__ sync, int lag) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NG = 64 / G, NGB = NG * WAVES, CAP = Stage4<G>::cap, WIN = G - 1;
+    constexpr int NG = 64 / G, NGB = NG * WAVES, CAP = Stage4<G>::cap, WIN = G - 1, UG = (CAP >= 8) ? kG4Unroll : kUnrollW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane & (G - 1), gid = wave * NG + lane / G;
     int* stage = reinterpret_cast<int*>(smem_raw) + gid * (2 * K * 2 * CAP);   // [buffer][user][ids CAP | weights CAP]
@@ -738,31 +742,34 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wmrb_gradu4(   // two
             const int* ids = stage + (buf * K + k) * 2 * CAP;
             const float* ws = reinterpret_cast<const float*>(ids + CAP);
             const int cnt = c_tot[k] < CAP ? c_tot[k] : CAP;
-            for (int e0 = 0; e0 < cnt; e0 += kUnrollW) {
-                static_assert((kUnrollW == 4 && CAP % 4 == 0) || CAP < 4, "vector LDS reads assume four entries per step");
-                Raw<NV, T> raw[kUnrollW];
-                float d[kUnrollW];
-                int idv[kUnrollW];
+            for (int e0 = 0; e0 < cnt; e0 += UG) {
+                static_assert(((UG == 4 || UG == 8) && CAP % UG == 0) || CAP < 4, "vector LDS reads assume four or eight entries per step");
+                Raw<NV, T> raw[UG];
+                float d[UG];
+                int idv[UG];
                 if constexpr (CAP >= 4) {
-                    const int4 id4 = *reinterpret_cast<const int4*>(ids + e0);
-                    const float4 w4 = *reinterpret_cast<const float4*>(ws + e0);
-                    idv[0] = id4.x; idv[1] = id4.y; idv[2] = id4.z; idv[3] = id4.w;
-                    d[0] = w4.x; d[1] = w4.y; d[2] = w4.z; d[3] = w4.w;
+#pragma unroll
+                    for (int q = 0; q < UG / 4; ++q) {
+                        const int4 id4 = *reinterpret_cast<const int4*>(ids + e0 + 4 * q);
+                        const float4 w4 = *reinterpret_cast<const float4*>(ws + e0 + 4 * q);
+                        idv[4 * q] = id4.x; idv[4 * q + 1] = id4.y; idv[4 * q + 2] = id4.z; idv[4 * q + 3] = id4.w;
+                        d[4 * q] = w4.x; d[4 * q + 1] = w4.y; d[4 * q + 2] = w4.z; d[4 * q + 3] = w4.w;
+                    }
                 } else {
 #pragma unroll
-                    for (int t = 0; t < kUnrollW; ++t) {
+                    for (int t = 0; t < UG; ++t) {
                         idv[t] = (e0 + t < CAP) ? ids[e0 + t] : a.item_base;
                         d[t] = (e0 + t < CAP) ? ws[e0 + t] : 0.f;
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < kUnrollW; ++t) {
+                for (int t = 0; t < UG; ++t) {
                     const bool want = e0 + t < cnt && d[t] != 0.f;   // slots past cnt hold the resident row with weight 0
                     if (!want) d[t] = 0.f;
                     load_raw<G, NV>(raw[t], V, want ? idv[t] : a.item_base, g);
                 }
 #pragma unroll
-                for (int t = 0; t < kUnrollW; ++t) {
+                for (int t = 0; t < UG; ++t) {
                     Frag<NV> y;
                     to_frag<NV>(y, raw[t]);
                     axpy<NV>(acc[k], d[t], y);
@@ -1316,7 +1323,7 @@ __global__ __launch_bounds__(64 * (kS5Waves + 1)) void k_wmrb_scores5(const int3
 // Flat streams on the slice-major grid ("scores6", round 5).  k_wmrb_scores3 pays for every (user, slice)
 // visit with three dependent round trips - offsets -> ids -> rows - and at the config-5 shard a visit is 9 rows at 4 MB slices:
 // with 128 slices it runs 69.5 ms against 59.5 with 64 although its fabric traffic falls from 437 to 256 GB
-// (profiles/r05_c5_slices.txt).  Here a workgroup takes one (slice, group of kS6Users users) CHUNK: the group's rows go to LDS
+// (profiles/r05_c5_shard.txt).  Here a workgroup takes one (slice, group of kS6Users users) CHUNK: the group's rows go to LDS
 // once (as in scores5), and the chunk's entries - interactions, then negatives, each by user and item - are ONE contiguous piece
 // of a stream prepared once per fit (_engine.Scores6Plan): packed (local user << 24 | item) ids and the place every score goes to.
 // One read of the chunk's bounds, then ids and rows: no per-user offsets, no per-visit row of U.  Inside a chunk the entries of a
@@ -1325,14 +1332,20 @@ __global__ __launch_bounds__(64 * (kS5Waves + 1)) void k_wmrb_scores5(const int3
 // Scores agree with k_wmrb_scores3 to rounding (the summation tree of scores5), exactly on dyadic data.
 // ---------------------------------------------------------------------------------------------
 namespace tmf {
+// Config-5 shard, scores ms (profiles/r05_c5_shard.txt item 2): TWO steps of 8 gathers in flight per lane group (110 VGPRs, 4 waves per
+// SIMD): 32 users / 2 waves 55.4 (4 MB slices), 52.7 (6 MB); ONE step in flight (68 VGPRs, 7 waves per SIMD): 32 / 2: 51.0, 32 / 4: 50.0,
+// 32 / 8: 50.1, 64 / 4: 50.2, 64 / 8: 49.6, 16 / 4: 50.6, 128 / 8: 49.4, 128 / 16: 50.5 - more waves beat more rows per wave.
 #ifndef TMF_S6_USERS
-#define TMF_S6_USERS 32
+#define TMF_S6_USERS 64
 #endif
 #ifndef TMF_S6_WAVES
-#define TMF_S6_WAVES 2
+#define TMF_S6_WAVES 8
 #endif
-constexpr int kS6Users = TMF_S6_USERS;    // users per chunk (their rows: 16 KB of LDS at 512-byte rows); at most 256 (8-bit local user)
-constexpr int kS6Waves = TMF_S6_WAVES;    // 4 lane groups: a chunk of ~290 entries is ~9 steps of 8 for each
+#ifndef TMF_S6_ROUNDS
+#define TMF_S6_ROUNDS 1
+#endif
+constexpr int kS6Users = TMF_S6_USERS;    // users per chunk (their rows: 32 KB of LDS at 512-byte rows); at most 256 (8-bit local user)
+constexpr int kS6Waves = TMF_S6_WAVES;    // 16 lane groups: a chunk of ~580 entries is ~4.5 steps of 8 for each
 
 template <int NV, typename T>
 __global__ __launch_bounds__(64 * kS6Waves) void k_wmrb_scores6(const int32_t* __restrict__ ids, const int32_t* __restrict__ outs,
@@ -1401,6 +1414,22 @@ __global__ __launch_bounds__(64 * kS6Waves) void k_wmrb_scores6(const int32_t* _
         const float sc = Reduce8x32::run(pr, lane);
         if (owner && d.o != kS5Pad) __builtin_nontemporal_store(sc, d.o >= 0 ? sp + d.o : p + ~d.o);
     };
+#if TMF_S6_ROUNDS == 1
+    // one step of 8 gathers in flight per lane group: 68 VGPRs, seven waves per SIMD
+    {
+        Raw<NV, T> yA[8];
+        Ids A = fetch(0);
+        for (int i = 0; i < rounds; ++i) {
+            Ids B = fetch(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gather(yA, A);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(yA, A);
+            A = B;
+        }
+        return;
+    }
+#endif
     // two rounds in flight per lane group, the ids of round i + 2 asked for BEFORE the rows of round i + 1 (as in scores5)
     Raw<NV, T> yA[8], yB[8];
     Ids A = fetch(0);
