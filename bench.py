@@ -296,7 +296,7 @@ def roofline_report(models, prof, pmc=None):
 
 
 # kernel symbol prefixes of the per-kernel timer names, for matching the committed PMC profile
-PMC_KERNELS = {'wmrb_scores': ('tmf::k_wmrb_scores', ''), 'wmrb_hinge': 'tmf::k_wmrb_hinge2', 'wmrb_gradu': 'tmf::k_wmrb_gradu3',
+PMC_KERNELS = {'wmrb_scores': ('tmf::k_wmrb_scores', ''), 'wmrb_hinge': 'tmf::k_wmrb_hinge2', 'wmrb_gradu': ('tmf::k_wmrb_gradu', ''),
                'wmrb_finish': 'tmf::k_wmrb_finish', 'wmrb_item_pass': ('tmf::k_wsum_', ''), 'wmrb_combine': 'tmf::k_combine_rows',
                'wmrb_user_pass': 'tmf::k_wmrb_user',
                # the two launches per epoch of one kernel, told apart by dispatch order in tools/profile_summary.py
