@@ -150,7 +150,8 @@ def init_table(rows, r, seed, dev):
 #             (or the cache-sized window the kernel is blocked into) once per sweep when it is cache-resident
 #             (<= 256 MiB Infinity Cache), every gathered row when it is not.
 # ---------------------------------------------------------------------------------------------
-def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, part_layers=None, u_sweeps=1, flat_streams=False):
+def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, part_layers=None, u_sweeps=1, flat_streams=False,
+                       v_sweeps=0):
     row = ld * s          # bytes of one factor row as stored
     row32 = ld * 4        # fp32 partial / gradient rows
     U_tab, V_tab = m * row, n * row
@@ -171,11 +172,16 @@ def wmrb_kernel_models(m, n, S, nnz, P, ld, s, ns, sliced, E_lists, n_slab, C, p
                                       'sampled + interaction scores: V rows gathered from the L2-resident slice, ids staged in LDS'))
         k['wmrb_hinge'] = dict(rows=0, gather=0, hbm=m * S * 4 + 2 * nnz * 4 + m * 8 + m * S * 4 + nnz * 4, roof='issue',
                                what='sort + binary search + scans per user (one wave per user); streams sp / p in, D / delta out')
-        k['wmrb_gradu'] = dict(rows=m * S + nnz, gather=(m * S + nnz) * row,
-                               hbm=2 * m * S * 4 + off + 2 * nnz * 4 + (V_tab if v_resident else (m * S + nnz) * row) + part_wr,
-                               roof='l2' if v_resident else 'hbm',
-                               what='D- and delta-weighted V rows per (user, slice); rows with weight 0 are skipped (but counted here)')
-        k['wmrb_finish'] = dict(rows=0, gather=0, hbm=layers * m * row32 + 2 * U_tab, roof='hbm', what='ordered sum of the slice partials + fresh Adam')
+        if v_sweeps:   # row-stationary gradU (tmf_wmrb_gradu4): no partial rows, no finish kernel; every launch of resident lane groups walks the whole catalog
+            k['wmrb_gradu'] = dict(rows=m * S + nnz, gather=(m * S + nnz) * row,
+                                   hbm=2 * m * S * 4 + off + 2 * nnz * 4 + v_sweeps * V_tab + 2 * U_tab, roof='l2' if v_resident else 'hbm',
+                                   what='row-stationary gradU + fresh Adam: lane groups own users, keep their gradient rows in registers and walk all slices')
+        else:
+            k['wmrb_gradu'] = dict(rows=m * S + nnz, gather=(m * S + nnz) * row,
+                                   hbm=2 * m * S * 4 + off + 2 * nnz * 4 + (V_tab if v_resident else (m * S + nnz) * row) + part_wr,
+                                   roof='l2' if v_resident else 'hbm',
+                                   what='D- and delta-weighted V rows per (user, slice); rows with weight 0 are skipped (but counted here)')
+            k['wmrb_finish'] = dict(rows=0, gather=0, hbm=layers * m * row32 + 2 * U_tab, roof='hbm', what='ordered sum of the slice partials + fresh Adam')
     else:
         k['wmrb_user_pass'] = dict(rows=2 * (m * S + nnz), gather=2 * (m * S + nnz) * row,
                                    hbm=m * S * 4 + 2 * nnz * 4 + 2 * U_tab + (V_tab if V_tab <= MALL_BYTES else 2 * (m * S + nnz) * row) + m * S * 4 + nnz * 4,
@@ -640,14 +646,15 @@ class Workload:
         st, p, w = self.st, self.plan, self.wplan
         s = 2 if self.dtype == 'bf16' else 4
         if self.loss == 'wmrb':
+            vs = -(-self.m // st.users_per_launch) if getattr(st, 'row_stationary', False) else 0
             if w.rows4:   # row-stationary item pass: slab = the parts of the cut rows, one sweep of U per launch of resident lane groups
                 work = w.vrows.n_vrows if w.vrows is not None else self.n
                 return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced, int(w.rowptr_e[-1]),
                                           w.vrows.n_slab if w.vrows is not None else 0, w.user_chunks, getattr(st, 'part_layers', None),
-                                          u_sweeps=max(2, -(-work // st.rows4_per_launch)), flat_streams=getattr(w, 's6', None) is not None)
+                                          u_sweeps=max(2, -(-work // st.rows4_per_launch)), flat_streams=getattr(w, 's6', None) is not None, v_sweeps=vs)
             return wmrb_kernel_models(self.m, self.n, self.S, self.nnz, p.n_pos, st.ld, s, w.n_slices, w.sliced,
                                       int(w.rowptr_e[-1]), w.seg_e.n_slab if w.seg_e is not None else 0, w.user_chunks,
-                                      getattr(st, 'part_layers', None), flat_streams=getattr(w, 's6', None) is not None)
+                                      getattr(st, 'part_layers', None), flat_streams=getattr(w, 's6', None) is not None, v_sweeps=vs)
         return mse_kernel_models(self.m, self.n, self.nnz, st.ld, s)
 
     def describe(self, tag):
