@@ -724,9 +724,9 @@ def strong_scaling_projection(args, dev, full_ms, full_kernel_ms, G=8, steps=10,
     tmf_adam_fresh_rows on the rank's 1/G of V) is measured; the wire time of the two collectives is MODELLED from their byte
     counts over 7 xGMI links; the 1-rank RCCL calls are measured only as a call floor (no peer: a device-local copy).
     The reference loop being split: /root/reference/src/teamoflow/mf/matrix_factorization.py:128-176.
-    Ten warm-up epochs (120 ms) before ten timed ones: the shard is prepared on the host for a second or two while the card idles,
-    and with two warm-up epochs of 12 ms the first timed kernels still ran at the idle clock (round 4: hinge 1.02 ms on the shard,
-    0.57 ms for the same 125,000 users as a problem of their own - profiles/r05_c5_shard.txt)."""
+    Ten warm-up epochs (120 ms) before ten timed ones: the card idles for a second or two while the shard is prepared on the host.
+    (That was not why round 4 saw the hinge kernel at 1.02 ms on the shard against 0.57 ms for the same users as a problem of their
+    own - it is 1.00 ms after ten warm-up epochs too; the kernel's time depends on how the scores cluster, profiles/r05_c5_shard.txt.)"""
     out = dict(label=f'PROJECTION from one GPU - no N > 1 run has been measured; G = {G}', G=G, full_problem_ms=full_ms, shards={})
     worst, worst_kernels = 0.0, {}
     for rank in (0, G - 1):
