@@ -107,3 +107,37 @@ def test_scores6_geometries(eng, monkeypatch):
         assert not eng.scores6_wanted(plan, w, r, dtype)
         monkeypatch.setenv('TMF_SCORES6', '1')
         assert eng.scores6_wanted(plan, w, r, dtype) == has_kernel, (n_items, r)
+
+
+def test_stated_catalog_size_is_checked_on_request(eng, monkeypatch):
+    """tmf_slice_lists.n_items switches the 32-bit-offset walk of tmf_wmrb_scores3 on - it counts only with
+    TMF_SLICE_N_ITEMS_STATED in `flags` (a caller built against the older, shorter struct passes indeterminate bytes there), and
+    TMF_CHECK_IDS=1 makes the call verify that every id of the lists is below it."""
+    import ctypes
+    from teamoflow_amd import _lib
+    lib = _lib.get()
+    m, n, r, S = 300, 5000, 128, 40
+    idx, val, R, U, V = problem(m, n, r, S, 4000, seed=3)
+    monkeypatch.setenv('TMF_SCORES6', '0')
+    monkeypatch.setenv('TMF_SCORES5', '0')
+    plan = eng.InteractionPlan(idx, val, m, n)
+    wplan = eng.WmrbPlan(plan, R, item_slices=3, n_components=r, sliced=True)
+    st = eng.TrainState(U, V, plan, r, wplan)
+
+    def lists(flags, n_items):
+        return _lib.SliceLists(wplan.R.data_ptr(), wplan.slice_off.data_ptr(), plan.rowptr_u.data_ptr(), plan.col_u.data_ptr(),
+                               wplan.pos_off.data_ptr(), m, S, 3, 0, 0, 0, flags, n_items)
+
+    def scores(sl):
+        return lib.tmf_wmrb_scores3_f32(ctypes.byref(sl), _lib.ptr(st.U), _lib.ptr(st.V), _lib.ptr(st.sp), _lib.ptr(st.pk), r, _lib.stream_ptr())
+    monkeypatch.setenv('TMF_CHECK_IDS', '1')
+    assert scores(lists(_lib.SLICE_N_ITEMS_STATED, n)) == 0                 # the true size: fine
+    want = st.sp.clone()
+    assert scores(lists(_lib.SLICE_N_ITEMS_STATED, n // 2)) != 0            # ids beyond the stated size: refused, with a count
+    assert b'outside [0, n_items' in lib.tmf_last_error()
+    # without the flag the field is ignored (garbage in it cannot switch the lean walk on, nor trip the check): same scores
+    st.sp.zero_()
+    assert scores(lists(0, 7)) == 0
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    assert float((st.sp - want).abs().max()) <= 2e-6 * scale
