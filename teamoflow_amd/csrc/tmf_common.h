@@ -498,45 +498,6 @@ __device__ __forceinline__ void step_rendezvous(int* sync, int i, int lag, int n
         __builtin_amdgcn_s_sleep(8);
     }
 }
-// The same rendezvous without the workgroup barrier (round 5): every WAVE waits for itself.  The row-stationary kernels keep nothing
-// in LDS that two waves share, so the barrier behind step_rendezvous served the pacing only - and held the waves of a workgroup in
-// lockstep: all of them in the bounds -> entries -> weights chain of a step at the same time, then all of them gathering rows, with
-// nothing to hide the one behind the other.  Here a wave that finishes step i counts itself in LDS; the last wave of the workgroup
-// publishes "this workgroup has finished step i" (one relaxed agent-scope add, as before); then the wave waits - bounded - until
-// step i - lag is complete for its XCD lane, which it learns from LDS (s_seen: the latest step some wave of the workgroup has seen
-// complete) or, failing that, from the counter itself.  Waves of a workgroup thus drift by up to lag + 1 steps against each other,
-// which is what the L2 window allows anyway.  Speed only: no data is handed over.
-struct WaveRendezvous {
-    int done[8];   // done[i & 7]: waves of this workgroup that have finished a step congruent to i mod 8 (never reset: after step i it
-                   // stands at waves x (i / 8 + 1); the waves of a workgroup are at most lag + 1 < 8 steps apart - they wait for their own
-                   // workgroup too - unless a wait timed out, and then only the pacing suffers)
-    int seen;      // latest step known complete for this workgroup's XCD lane
-};
-__device__ __forceinline__ void wave_rendezvous_init(WaveRendezvous& r) {
-    if (threadIdx.x < 8) r.done[threadIdx.x] = 0;
-    if (threadIdx.x == 0) r.seen = -1;
-    __syncthreads();
-}
-__device__ __forceinline__ void wave_rendezvous(int* sync, WaveRendezvous& r, int i, int lag, int n_groups, int waves) {
-    if ((threadIdx.x & 63) == 0) {
-        const int x = blockIdx.x & 7;
-        const int mine = (n_groups - x + 7) / 8;   // workgroups of this lane
-        const int d = __hip_atomic_fetch_add(&r.done[i & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
-        if (d == waves * ((i >> 3) + 1)) __hip_atomic_fetch_add(sync + (i * 8 + x) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int need = i - lag;
-        if (need >= 0) {
-            for (int spin = 0; spin < 256; ++spin) {
-                if (__hip_atomic_load(&r.seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
-                if (__hip_atomic_load(sync + (need * 8 + x) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine) {
-                    __hip_atomic_fetch_max(&r.seen, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
 inline size_t rendezvous_bytes(int64_t launches, int64_t steps) {
     return (size_t)launches * (size_t)steps * 8 * kSyncStride * sizeof(int);
 }

@@ -326,9 +326,6 @@ constexpr int kRows4Unroll2 = TMF_ROWS4_UNROLL, kRows4Unroll1 = 4;   // rows in 
 #ifndef TMF_ROWS4_K2
 #define TMF_ROWS4_K2 6
 #endif
-#ifndef TMF_WAVE_RDV
-#define TMF_WAVE_RDV 1   // 1: every wave waits for itself (wave_rendezvous); 0: one thread + a workgroup barrier per step (rounds 3-4)
-#endif
 #ifndef TMF_ROWS4_WAVES
 #define TMF_ROWS4_WAVES 8
 #endif
@@ -373,10 +370,6 @@ __global__ __launch_bounds__(64 * WAVES, TMF_ROWS4_MINW) void k_wsum_rows4(
     Frag<NV> acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) zero<NV>(acc[k]);
-#if TMF_WAVE_RDV
-    __shared__ WaveRendezvous s_rdv;
-    wave_rendezvous_init(s_rdv);
-#endif
     // lane l <= kv describes the boundary "first entry of (virtual) row j0 + l"; lanes beyond kv repeat the last one
     const bool balanced = vr.item != nullptr;
     const int64_t vq = j0 + (g < kv ? g : kv);
@@ -435,12 +428,8 @@ __global__ __launch_bounds__(64 * WAVES, TMF_ROWS4_MINW) void k_wsum_rows4(
             }
             wave_lds_sync();   // the next tile rewrites the stage
         }
-#if TMF_WAVE_RDV
-        if (sync != nullptr) wave_rendezvous(sync, s_rdv, t, lag, (int)gridDim.x, WAVES);
-#else
         if (sync != nullptr && tid == 0) step_rendezvous(sync, t, lag, (int)gridDim.x);
         __syncthreads();
-#endif
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {

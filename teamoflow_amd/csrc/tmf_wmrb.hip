@@ -19,9 +19,6 @@ namespace tmf {
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kPosChunk = 512;
-#ifndef TMF_WAVE_RDV
-#define TMF_WAVE_RDV 1   // see tmf_train.hip / tmf_common.h wave_rendezvous
-#endif
 constexpr int kUnrollW = 4;
 #ifndef TMF_G4_UNROLL
 #define TMF_G4_UNROLL 4
@@ -730,10 +727,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wmrb_gradu4(   // two
         }
         wave_lds_sync();
     };
-#if TMF_WAVE_RDV
-    __shared__ WaveRendezvous s_rdv;
-    wave_rendezvous_init(s_rdv);
-#endif
     refill(a.sl0);
     fetch(a.sl0);
     commit(0);
@@ -799,12 +792,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void k_wmrb_gradu4(   // two
             }
         }
         if (more) commit(buf ^ 1);
-#if TMF_WAVE_RDV
-        if (sync != nullptr) wave_rendezvous(sync, s_rdv, sl - a.sl0, lag, (int)gridDim.x, WAVES);   // the stage is private to the wave
-#else
         if (sync != nullptr && tid == 0) step_rendezvous(sync, sl - a.sl0, lag, (int)gridDim.x);
         __syncthreads();   // lockstep of the workgroup's lane groups (the other buffer is private to this wave: no hazard)
-#endif
     }
 #pragma unroll
     for (int k = 0; k < K; ++k)
