@@ -588,7 +588,7 @@ class Scores6Plan:
     PAD = -2 ** 31
 
     def __init__(self, plan, wplan, n_components, dtype=torch.float32, slice_bytes=None):
-        lib = _lib.get()
+        lib = _lib.load_library()   # the builder itself needs no GPU (tests/test_host_cpu.py runs it on CPU tensors)
         dev = plan.col_u.device
         self.key = (int(n_components), dtype)
         UG = int(lib.tmf_wmrb_scores6_users_per_group())

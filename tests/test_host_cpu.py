@@ -298,3 +298,51 @@ def test_virtual_rows_of_the_balanced_item_pass():
     for P in (1, 2, 5, 11, 40):
         cuts = [p * L // P for p in range(P + 1)]
         assert cuts[0] == 0 and cuts[-1] == L and all(a <= b for a, b in zip(cuts, cuts[1:]))
+
+
+def test_scores6_entry_streams_on_the_host():
+    """_engine.Scores6Plan (the streams tmf_wmrb_scores6 walks), built on CPU tensors: every score the epoch needs - negative (u, pos)
+    of the item-sorted table, interaction k of the CSR - appears exactly once, in the chunk of its (item slice, user group), with
+    the right packed id and place; inside a chunk the interactions come first, then the negatives, each by user and item; chunks
+    are padded to steps of 8 with the PAD place."""
+    import torch
+    from teamoflow_amd import _engine as E, _lib
+    g = torch.Generator().manual_seed(5)
+    m, n, r, S = 150, 900, 128, 24
+    key = torch.unique(torch.randint(0, m, (2500,), generator=g) * n + torch.randint(0, n, (2500,), generator=g))
+    idx = torch.stack([key // n, key % n], 1)
+    val = torch.randint(-1, 6, (key.numel(),), generator=g).float()
+    R = torch.stack([torch.randperm(n, generator=g)[:S] for _ in range(m)]).to(torch.int32)
+    plan = E.InteractionPlan(idx, val, m, n)
+    wplan = E.WmrbPlan(plan, R, item_slices=3, n_components=r, sliced=True)
+    s6 = E.Scores6Plan(plan, wplan, r, torch.float32, slice_bytes=100 * 512)      # slices of 100 items: 9 of them
+    UG = _lib.load_library().tmf_wmrb_scores6_users_per_group()
+    ng, ns = s6.n_groups, s6.n_slices
+    assert ng == -(-m // UG) and ns == 9 and s6.chunk_ptr.numel() == ns * ng + 1
+    width = -(-n // ns)
+    ptr, ids, outs = s6.chunk_ptr.tolist(), s6.ids.tolist(), s6.outs.tolist()
+    assert all(p % 8 == 0 for p in ptr) and ptr[-1] == s6.n_padded and len(ids) == s6.n_padded + 8
+    Rs, user_of, col = wplan.R.tolist(), plan.user_of.tolist(), plan.col_u.tolist()
+    seen_neg, seen_pos = set(), set()
+    for c in range(ns * ng):
+        sl, grp = divmod(c, ng)
+        real = [(ids[e], outs[e]) for e in range(ptr[c], ptr[c + 1]) if outs[e] != E.Scores6Plan.PAD]
+        pads = [e for e in range(ptr[c], ptr[c + 1]) if outs[e] == E.Scores6Plan.PAD]
+        assert len(pads) < 8 and all(e >= ptr[c] + len(real) for e in pads)        # padding sits behind the chunk's entries
+        order = []
+        for pid, out in real:
+            u, item = grp * UG + ((pid >> 24) & 0xff), pid & 0xffffff
+            assert item // width == sl and u < m
+            if out >= 0:
+                assert Rs[out // S][out % S] == item and out // S == u and out not in seen_neg
+                seen_neg.add(out)
+                order.append((1, u, item))
+            else:
+                k = ~out
+                assert user_of[k] == u and col[k] == item and k not in seen_pos
+                seen_pos.add(k)
+                order.append((0, u, item))
+        assert order == sorted(order)                                              # interactions, then negatives; each by user and item
+        for e in pads:                                                             # a padding entry repeats a valid id of the chunk
+            assert (ids[e] & 0xffffff) // width == sl
+    assert len(seen_neg) == m * S and len(seen_pos) == plan.nnz
