@@ -22,19 +22,10 @@ def ns():
     from teamoflow_amd.mf.sparse import SparseInteractions
     _lib.get()
 
-    class HostFixed(I.Initializer):
-        """Weights that stay on the host: the generic loop then runs on CPU torch (the comparison run)."""
-
-        def __init__(self, w):
-            self.w = w
-
-        def initialize_weights(self, n_features, n_components):
-            return torch.tensor(np.asarray(self.w, np.float32)).clone().requires_grad_(True)
-
     class NS:
         pass
     o = NS()
-    o.E, o.I, o.L, o.MF, o.Sparse, o.HostFixed = E, I, L, MatrixFactorization, SparseInteractions, HostFixed
+    o.E, o.I, o.L, o.MF, o.Sparse = E, I, L, MatrixFactorization, SparseInteractions
     return o
 
 
