@@ -77,8 +77,11 @@ BF16_UPCAST_USERS = 1 << 18   # users per call when bf16 tables are ranked throu
 PREDICT_ARITHMETIC = os.environ.get('TMF_PREDICT_ARITHMETIC', 'auto')   # 'auto' | 'fp32' | 'split' | 'half2'
 
 
+SPLIT_MAX_R = 256   # the three-plane kernel: 96 A registers per lane at r = 128, 192 at r = 256 (eight waves per workgroup, two per SIMD)
+
+
 def split_topk_supported(r, k):
-    return 1 <= r <= 128 and 1 <= k <= 32
+    return 1 <= r <= SPLIT_MAX_R and 1 <= k <= 32
 
 
 def half2_topk_supported(r, k):
@@ -108,7 +111,7 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
     fp32 tables: 'fp32' = fp32 MFMA (k <= 64, width <= 256, bit-equal to an fmaf chain); 'split' = the bf16 matrix cores with ALL
     24 significand bits of every factor (three exact bf16 planes per factor, six plane products each exact in the fp32
-    accumulator; ~1.9x the rate of the fp32 kernel, errors against fp64 at or below its; width <= 128, k <= 32).
+    accumulator; ~1.9x the rate of the fp32 kernel, errors against fp64 at or below its; width <= 256 - 1.55x the fp32 kernel at 256: 171 against 110 TF -, k <= 32).
     'auto' (the default) takes 'split' where it applies and the job has SPLIT_MIN_SCORES scores or more, else 'fp32' - both keep
     the reference's fp32 operands whole (tf.matmul on fp32, matrix_factorization.py:236-248, 424-438).
     'half2' is an OPT-IN approximation, never chosen by 'auto': two fp16 planes under power-of-two scales = 22 bits of every
@@ -179,7 +182,7 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
     if (arithmetic == 'split' and not split_topk_supported(r, k)) or (arithmetic == 'half2' and not half2_topk_supported(r, k)):
-        raise ValueError(f'the split kernels support widths <= 128 (half2: 256) and k <= 32 (got {r}, {k})')
+        raise ValueError(f'the split kernels support widths <= 256 and k <= 32 (got {r}, {k})')
     if arithmetic == 'auto':
         arithmetic = 'split' if m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k) else 'fp32'
         planes_optional = True    # 'auto' may fall back to the fp32 kernel (it needs no workspace) when memory is short

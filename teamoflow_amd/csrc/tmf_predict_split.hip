@@ -26,6 +26,9 @@
 // and the epilogue takes out of the values.  Half the matrix-core work, 64 instead of 96 A registers at r = 128 (r <= 256
 // fits), values against fp64 at the fp32 MFMA kernel's error: 19.9 ms = 338 TF fp32-equivalent at r = 128 (item 7 of the notes).
 //
+// Round 5: r <= 256 on the three bf16 planes too (192 A registers per lane, 64-item tiles, some spills outside the chunk loop, eight
+// waves per workgroup at two per SIMD): 262144 x 100000, k = 10: 78.5 ms = 170.9 TF fp32-equivalent against 121.8 ms = 110.2 TF for the
+// fp32 MFMA kernel, same error against fp64 (7.0e-7), lists identical (tools/time_predict_r256.py).
 // Measured (262144 x 100000, k = 10, random factors; tools/split_time.py, profiles/r03_predict_split.txt): r = 128: 29.9 ms =
 // 224.7 TF fp32-equivalent = 1.35 PFLOP/s of bf16 MFMA work (fp32 MFMA kernel: 57 ms, 118 TF); r = 64: 195 TF; r = 32: 149 TF.
 // Timing-only variants of the r = 128 run: without the candidate handling 27.3 ms, also without the chunk barrier 28.4 (no
@@ -48,7 +51,7 @@ typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_s;
 typedef __attribute__((address_space(1))) const void gbl_void_s;
 
-constexpr int SMAXK = 32, SMAXR = 128, SMAXR_HALF2 = 256;
+constexpr int SMAXK = 32, SMAXR = 256, SMAXR_HALF2 = 256;
 // Two shapes of workgroup.  WAVES = 4 (128 users, two workgroups per CU, k <= 22): the workgroups of a CU drift
 // apart, so one multiplies while the other stands at its chunk barrier or files candidates - the two waves of a SIMD no longer
 // stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop, for k > 22
@@ -575,7 +578,8 @@ static int launch_predict_topk_split(int ldp, int k, const float* A, const uint1
     } else {
         if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
         if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
-        TMF_SPLIT_GO(2, 4, 2);
+        if (ldp == 128) { TMF_SPLIT_GO(2, 4, 2); }
+        TMF_SPLIT_GO(2, 4, 4);   // r <= 256 (round 5): 192 A registers - eight waves per workgroup, two per SIMD, 256 VGPRs each
     }
 #undef TMF_SPLIT_GO
 }

@@ -70,7 +70,7 @@ def test_default_ranking_equals_tf_top_k_on_the_golden_tables(ops, monkeypatch, 
 
 
 def test_auto_never_takes_the_two_plane_form(ops, monkeypatch):
-    """From 2^26 scores on 'auto' runs the three-plane kernel (width <= 128, k <= 32) or the fp32 MFMA - never half2, whatever
+    """From 2^26 scores on 'auto' runs the three-plane kernel (width <= 256, k <= 32) or the fp32 MFMA - never half2, whatever
     the range of the item rows; half2 still answers when asked for by name."""
     from teamoflow_amd import _lib
     lib = _lib.get()

@@ -33,7 +33,7 @@ def test_exact_on_small_integer_factors(ops, seed, arith):
     rng = np.random.default_rng(4100 + seed)
     m = int(rng.integers(1, 600))
     n = int(rng.choice([1, 7, 128, 129, 1000, 4097, 16384, 20011, 33000, 40000]))
-    r = int(rng.choice([1, 3, 8, 31, 32, 33, 50, 64, 65, 100, 127, 128]))
+    r = int(rng.choice([1, 3, 8, 31, 32, 33, 50, 64, 65, 100, 127, 128, 129, 192, 255, 256]))
     k = int(min(n, rng.choice([1, 2, 5, 10, 16, 17, 32])))
     span = int(rng.choice([1, 2, 4]))
     U = rng.integers(-span, span + 1, (m, r)).astype(np.float32)
@@ -119,21 +119,27 @@ def test_half2_keeps_22_bits_per_value(ops):
     assert np.all(np.abs(got - xs) <= 2.0 ** -21 * np.abs(xs))
 
 
+@pytest.mark.parametrize('arith', ['half2', 'split'])
 @pytest.mark.parametrize('r', [129, 200, 256])
-def test_half2_wide_tables(ops, r):
-    """The fp16 form reaches width 256 (128 A registers per lane): exact on integer factors, fp32-accurate on Gaussian ones."""
+def test_wide_tables(ops, r, arith):
+    """Both plane forms reach width 256 (fp16: 128 A registers per lane; bf16 x 3 since round 5: 192, eight waves per workgroup at two
+    per SIMD): exact on integer factors, fp32-accurate on Gaussian ones, with clamping and both workgroup shapes (k = 10: 4 waves,
+    k = 30: 8 waves)."""
     rng = np.random.default_rng(r)
-    m, n, k = 300, 33001, 10
-    U = rng.integers(-2, 3, (m, r)).astype(np.float32)
-    V = rng.integers(-2, 3, (n, r)).astype(np.float32)
-    sc = U @ V.T
-    vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, return_values=True, arithmetic='half2')
-    ref = expected(sc, k, False)
-    assert np.array_equal(got.cpu().numpy(), ref) and np.array_equal(vals.cpu().numpy(), np.take_along_axis(sc, ref, 1))
+    m, n = 300, 33001
+    for k, clamp in ((10, False), (30, True)):
+        U = rng.integers(-2, 3, (m, r)).astype(np.float32)
+        V = rng.integers(-2, 3, (n, r)).astype(np.float32)
+        sc = U @ V.T
+        vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic=arith)
+        ref = expected(sc, k, clamp)
+        assert np.array_equal(got.cpu().numpy(), ref), (r, k, arith)
+        assert np.array_equal(vals.cpu().numpy(), np.take_along_axis(np.where(sc > 0, sc, 0) if clamp else sc, ref, 1))
+    k = 10
     g = torch.Generator().manual_seed(r)
     Ug, Vg = torch.randn(m, r, generator=g) * 0.05, torch.randn(n, r, generator=g) * 0.05
     want = Ug.double() @ Vg.double().T
-    vh, ih = ops.predict_topk(Ug, Vg, k, return_values=True, arithmetic='half2')
+    vh, ih = ops.predict_topk(Ug, Vg, k, return_values=True, arithmetic=arith)
     v32, i32 = ops.predict_topk(Ug, Vg, k, return_values=True, arithmetic='fp32')
     norm = float(want.abs().max())
     eh = float((vh.cpu().double() - torch.gather(want, 1, ih.cpu().long())).abs().max()) / norm
@@ -141,6 +147,7 @@ def test_half2_wide_tables(ops, r):
     assert eh < 1.5e-6 and eh <= 2 * e32 + 2e-7, (eh, e32)
     lib = __import__('teamoflow_amd._lib', fromlist=['get']).get()
     assert lib.tmf_predict_topk_half2_supported(256, 32) == 1 and lib.tmf_predict_topk_half2_supported(257, 1) == 0
+    assert lib.tmf_predict_topk_split_supported(256, 32) == 1 and lib.tmf_predict_topk_split_supported(257, 1) == 0
 
 
 def test_half2_range_guard(ops):
@@ -181,11 +188,12 @@ def test_deferred_merges_and_overflow(ops, arith):
 def test_limits_and_errors(ops):
     from teamoflow_amd import _lib
     lib = _lib.get()
-    assert lib.tmf_predict_topk_split_supported(128, 32) == 1 and lib.tmf_predict_topk_split_supported(129, 10) == 0
-    assert lib.tmf_predict_topk_split_supported(64, 33) == 0 and lib.tmf_predict_topk_split_workspace_bytes(1000, 129) == 0
+    assert lib.tmf_predict_topk_split_supported(256, 32) == 1 and lib.tmf_predict_topk_split_supported(257, 10) == 0
+    assert lib.tmf_predict_topk_split_supported(64, 33) == 0 and lib.tmf_predict_topk_split_workspace_bytes(1000, 257) == 0
+    assert lib.tmf_predict_topk_split_workspace_bytes(1000, 129) == 3 * 1024 * 256 * 2
     assert lib.tmf_predict_topk_split_workspace_bytes(1000, 100) == 3 * 1024 * 128 * 2
     with pytest.raises(ValueError):
-        ops.predict_topk(torch.ones(4, 200), torch.ones(9, 200), 2, arithmetic='split')
+        ops.predict_topk(torch.ones(4, 300), torch.ones(9, 300), 2, arithmetic='split')
     with pytest.raises(ValueError):
         ops.predict_topk(torch.ones(4, 8), torch.ones(99, 8), 40, arithmetic='split')
     x = torch.ones(8, 8, device='cuda')
@@ -194,8 +202,8 @@ def test_limits_and_errors(ops):
     rc = lib.tmf_predict_topk_split_f32(_lib.ptr(x), _lib.ptr(x), 8, 8, 8, 8, 8, 2, 0, _lib.ptr(out), None, _lib.ptr(ws), 64,
                                         _lib.stream_ptr())
     assert rc != 0 and b'workspace' in lib.tmf_last_error()
-    big = torch.ones(4, 132, device='cuda')
-    rc = lib.tmf_predict_topk_split_f32(_lib.ptr(big), _lib.ptr(big), 4, 4, 130, 132, 132, 2, 0, _lib.ptr(out), None, _lib.ptr(ws), 64,
+    big = torch.ones(4, 260, device='cuda')
+    rc = lib.tmf_predict_topk_split_f32(_lib.ptr(big), _lib.ptr(big), 4, 4, 258, 260, 260, 2, 0, _lib.ptr(out), None, _lib.ptr(ws), 64,
                                         _lib.stream_ptr())
     assert rc != 0 and b'supports' in lib.tmf_last_error()
     assert lib.tmf_predict_topk_split_f32(None, None, 0, 5, 4, 4, 4, 1, 0, None, None, None, ctypes.c_size_t(0), _lib.stream_ptr()) == 0

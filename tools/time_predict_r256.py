@@ -4,7 +4,7 @@ from teamoflow_amd import _ops
 m, n, r, k = 262144, 100000, 256, 10
 U = torch.randn(m, r, device='cuda') * 0.05; V = torch.randn(n, r, device='cuda') * 0.05
 ref = U[:1024].double() @ V.double().T
-for arith in ('fp32', 'half2'):
+for arith in ('fp32', 'split', 'half2'):
     v, i = _ops.predict_topk(U[:1024], V, k, return_values=True, arithmetic=arith)
     err = float((v.double() - torch.gather(ref, 1, i.long())).abs().max() / ref.abs().max())
     same = float((i.long() == torch.topk(ref, k, dim=1)[1]).all(1).float().mean())
