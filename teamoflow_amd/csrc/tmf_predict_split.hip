@@ -574,7 +574,11 @@ static int launch_predict_topk_split(int ldp, int k, const float* A, const uint1
         if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
         if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
         if (ldp == 128) { TMF_SPLIT_GO(4, 2, 4); }
-        TMF_SPLIT_GO(2, 4, 4);   // r <= 256: 128 A registers, 64-item tiles
+        // r <= 256: 128 A registers, 64-item tiles - on the 4-wave workgroups for every k.  The 8-wave instance of this shape
+        // (k > 22) returned wrong lists for every row (found in round 5 when the wide-table test got a k = 30 case:
+        // tools/half2_diag.py; the bf16 form of the same shape and the fp16 form at r <= 128 are right); 128 users' lists fit the
+        // LDS up to k = 32 beside the ring, so the shape that is tested is the one that runs.
+        return launch_predict_topk_split_w<2, 4, 4, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
     } else {
         if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
         if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
