@@ -542,12 +542,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_predict_topk
 static int64_t split_rows_pad(int64_t n) { return (n + kSplitRowsPad - 1) / kSplitRowsPad * kSplitRowsPad; }
 static int split_ldp(int r) { return r <= 32 ? 32 : r <= 64 ? 64 : r <= 128 ? 128 : 256; }
 
+#ifndef TMF_SPLIT_LDS_PAD
+#define TMF_SPLIT_LDS_PAD 0   /* timing-only: LDS bytes asked for beyond what the kernel uses (45000: one 4-wave workgroup per CU) */
+#endif
 template <int NJ, int KS, int NCH, int WAVES, bool HALF2>
 static int launch_predict_topk_split_w(const float* A, const uint16_t* Bp, int64_t m, int64_t n, int64_t n_pad, int K, int64_t lda,
                                        int k, int clamp, int32_t* out_idx, float* out_val, const float* item_scale, hipStream_t stream) {
     constexpr int SBM = 32 * WAVES, SRING = split_ring(WAVES, HALF2), NP = HALF2 ? 2 : 3;
     const size_t lds = (size_t)SRING * NP * (32 * NJ) * (32 * KS) + 3 * sizeof(float) * SBM + 8 * (size_t)split_cap(WAVES, k) * SBM +
-                       8 * (size_t)k * SBM;
+                       8 * (size_t)k * SBM + TMF_SPLIT_LDS_PAD;
     static LdsGrant grant;  // per template instance
     if (int rc = grant_dynamic_lds(reinterpret_cast<const void*>(&k_predict_topk_split<NJ, KS, NCH, WAVES, HALF2>), lds, grant)) return rc;
     const int64_t blocks = (m + SBM - 1) / SBM;
