@@ -991,7 +991,7 @@ static int wmrb_gradu3_impl(const tmf_slice_lists* lists, const float* D, const 
     const int waves = slice_waves(lists, geom.G);
     if (int rc = check_lists(lists, a, "wmrb_gradu3", geom.G, waves)) return rc;
     if (a.n_users == 0) return TMF_OK;
-    TMF_REQUIRE(D && delta && V && part, "wmrb_gradu3: null pointer");
+    TMF_REQUIRE(D && V && part && (delta || lists->col == nullptr), "wmrb_gradu3: null pointer");   // no interactions at all: no delta either
     const size_t lds = slice_lds(geom, waves);
     TMF_REQUIRE(per_slice_launches >= 0 && per_slice_launches <= 3, "wmrb_gradu3: per_slice_launches=%d", per_slice_launches);
     if (per_slice_launches == 3) {   // rounds of eight slices, one layer per XCD lane (see k_wmrb_gradu3)
@@ -1066,7 +1066,7 @@ static int wmrb_gradu4_impl(const tmf_slice_lists* lists, const float* D, const 
     constexpr int W4 = 8;
     if (int rc = check_lists(lists, a, "wmrb_gradu4", geom.G, W4)) return rc;
     if (a.n_users == 0) return TMF_OK;
-    TMF_REQUIRE(D && delta && V && U_out && (epi == TMF_EPI_GRAD || U_old), "wmrb_gradu4: null pointer");
+    TMF_REQUIRE(D && V && U_out && (delta || lists->col == nullptr) && (epi == TMF_EPI_GRAD || U_old), "wmrb_gradu4: null pointer");
     TMF_REQUIRE(epi == TMF_EPI_ADAM || epi == TMF_EPI_GRAD, "wmrb_gradu4: bad epilogue %d", epi);
     TMF_REQUIRE(users_per_launch > 0, "wmrb_gradu4: users_per_launch=%d", users_per_launch);
     if (geom.G < 8) {   // the offsets cache holds G slices per refill

@@ -190,3 +190,37 @@ def test_random_forms_at_medium_size_against_the_plain_forms(eng, monkeypatch, s
     c = one_epoch(eng, monkeypatch, env, *args)     # and every form is reproducible bit for bit
     for k in ('gU', 'gV', 'U', 'V', 'D'):
         assert torch.equal(b[k], c[k]), (k, what)
+
+
+@pytest.mark.parametrize('forms', [dict(), dict(TMF_SCORES6='1'), dict(TMF_ROW_STATIONARY='1'), dict(TMF_ROWS4='1'),
+                                   dict(TMF_ROWS4='1', TMF_ROWS5='0'), dict(TMF_SCORES6='1', TMF_ROW_STATIONARY='1', TMF_ROWS4='1')])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_no_interactions_at_all(eng, monkeypatch, forms, dtype):
+    """An interaction table without a single entry (found by the round-5 soak on the windowed path: the per-interaction arrays are
+    then NULL): every loss term is gone, both gradients are zero and the fresh-Adam step leaves the tables as they are
+    (matrix_factorization.py:160-183: the mean of no losses is NaN, which the caller reports; the sum here is 0)."""
+    from teamoflow_amd import _lib
+    m, n, r, S = 300, 500, 128, 20
+    g = torch.Generator().manual_seed(1)
+    idx, val = torch.zeros(0, 2, dtype=torch.int64, device='cuda'), torch.zeros(0, device='cuda')
+    R = torch.stack([torch.randperm(n, generator=g)[:S] for _ in range(m)]).to(torch.int32).cuda()
+    U, V = (torch.randn(m, r, generator=g) * 0.3).cuda(), (torch.randn(n, r, generator=g) * 0.3).cuda()
+    for k in FORM_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    env = dict(PLAIN, TMF_ITEM_SLICES='3', TMF_USER_CHUNKS='2')
+    env.update(forms)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    plan = eng.InteractionPlan(idx, val, m, n)
+    wplan = eng.wmrb_plan_for(plan, R, r, dtype)
+    st = eng.TrainState(U, V, plan, r, wplan, dtype=dtype)
+    adam = eng.adam_constants(0.05)
+    loss = torch.ones(1, dtype=torch.float64, device='cuda')
+    gU = torch.full((m, st.ld), 7.0, device='cuda')
+    gV = torch.full((n, st.ld), 7.0, device='cuda')
+    eng.epoch_wmrb(st, adam, n / S, loss, item_epi=_lib.EPI_GRAD, item_out=gV, user_epi=_lib.EPI_GRAD, user_out=gU)
+    eng.epoch_wmrb(st, adam, n / S, loss)
+    torch.cuda.synchronize()
+    assert float(loss) == 0.0 and not gU[:, :r].any() and not gV[:, :r].any()
+    assert torch.equal(st.U_nxt[:, :r], st.U[:, :r]) and torch.equal(st.V_nxt[:, :r], st.V[:, :r])
+    assert not wplan.D.any()

@@ -292,6 +292,19 @@ def test_randomized_windowed_shapes_against_oracle(tm, monkeypatch, seed):
     assert_step(model.item_embedding.cpu().numpy(), V0, t['gV'], lr, what=f'{loss} V', slack=sV)
 
 
+@pytest.mark.parametrize('loss', ['mse', 'wmrb'])
+def test_windowed_fit_without_a_single_interaction(tm, loss):
+    """Seeds 249 / 259 of the 300-seed soak (a 3-item catalog whose last three items have no interactions): the per-interaction
+    arrays are NULL, the windowed WMRB pass refused them.  No loss term, no gradient: the tables stay, the mean of no losses is NaN
+    (matrix_factorization.py:160-183)."""
+    m, n, r, Sn = 84, 3, 128, 1
+    idx, val, U0, V0, R = problem(5, m, n, r, Sn, density=0.1)
+    assert len(val) == 0
+    model = fit(tm, U0, V0, idx, val, (m, n), 2, 0.05, loss, R, Sn, 8)
+    assert np.array_equal(model.user_embedding.cpu().numpy(), U0) and np.array_equal(model.item_embedding.cpu().numpy(), V0)
+    assert all(np.isnan(x) for x in model.loss_history_)
+
+
 def test_two_ranks_item_sharded_bf16_rows(tmp_path):
     """The same two-rank rehearsal with bf16 factor storage (config 5's format): bf16 windows through the all-gather, fp32
     gradients through the reduce-scatter.  Rounding to bf16 after differently ordered sums moves a few elements by one bf16
