@@ -366,6 +366,26 @@ def test_empty_interactions_leave_tables_unchanged(tm):
     assert all(np.isnan(x) for x in model.loss_history_)
 
 
+@pytest.mark.parametrize('force', [None, 'TMF_FORCE_SLICED', 'TMF_FORCE_FUSED'])
+def test_empty_interactions_leave_tables_unchanged_wmrb(tm, monkeypatch, force):
+    """The same with the WMRB loss, on the one-kernel and on the sliced user pass: no positive, no loss term, no gradient."""
+    for k in ('TMF_FORCE_SLICED', 'TMF_FORCE_FUSED', 'TMF_ITEM_SLICES'):
+        monkeypatch.delenv(k, raising=False)
+    if force:
+        monkeypatch.setenv(force, '1')
+    rng = np.random.default_rng(3)
+    m, n, r, S = 40, 60, 16, 7
+    U0 = rng.standard_normal((m, r)).astype(np.float32)
+    V0 = rng.standard_normal((n, r)).astype(np.float32)
+    R = np.stack([rng.choice(n, S, replace=False) for _ in range(m)])
+    for idx, val in ((np.zeros((0, 2), np.int64), np.zeros(0, np.float32)),
+                     (np.array([[3, 5], [7, 1]]), np.array([0.0, -2.0], np.float32))):      # stored values, none of them positive
+        model = fit_model(tm, U0, V0, idx, val, (m, n), 2, 0.01, 'wmrb', R, n, S)
+        assert np.array_equal(model.user_embedding.cpu().numpy(), U0)
+        assert np.array_equal(model.item_embedding.cpu().numpy(), V0)
+        assert all(np.isnan(x) for x in model.loss_history_)
+
+
 def test_topk_tie_rule_and_clamp(tm):
     x = torch.tensor([[0., 1, 1, 0, 1], [-1., -2, -3, -4, -5]])
     assert tm.ops.topk_stable(x, 3).cpu().tolist() == [[1, 2, 4], [0, 1, 2]]
