@@ -393,8 +393,8 @@ int tmf_predict_topk_bf16(const void* A, const void* B, int64_t m, int64_t n, in
 /* tmf_predict_topk_f32 for fp32 tables on the bf16 matrix cores, fp32-accurate: every factor is split exactly into three
  * bf16 planes and a score is the sum of the six plane products that weigh >= 2^-24 of the leading one, small ones first,
  * accumulated in fp32 (csrc/tmf_predict_split.hip; errors against fp64 at or below those of the fp32 MFMA kernel).  Same
- * outputs, order and tie rule as tmf_predict_topk_f32; values may differ from it by fp32 rounding.  r <= 256 (since version 203; 128 before), k <= 32
- * (tmf_predict_topk_split_supported); `workspace` holds the item table's planes (query the size; overwritten per call). */
+ * outputs, order and tie rule as tmf_predict_topk_f32; values may differ from it by fp32 rounding.  r <= 256 (since version 203; 128 before), k <= 40 (32 before the 4-wave
+ * instances of round 5: ask tmf_predict_topk_split_supported); `workspace` holds the item table's planes (query the size; overwritten per call). */
 int tmf_predict_topk_split_supported(int r, int k);
 size_t tmf_predict_topk_split_workspace_bytes(int64_t n, int r);
 int tmf_predict_topk_split_f32(const float* A, const float* B, int64_t m, int64_t n, int r, int64_t lda,

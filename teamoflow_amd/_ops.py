@@ -77,11 +77,12 @@ BF16_UPCAST_USERS = 1 << 18   # users per call when bf16 tables are ranked throu
 PREDICT_ARITHMETIC = os.environ.get('TMF_PREDICT_ARITHMETIC', 'auto')   # 'auto' | 'fp32' | 'split' | 'half2'
 
 
+SPLIT_MAX_K = 40    # two 4-wave workgroups' lists fit a CU's LDS beside their pending buffers up to k = 40 (tmf_predict_split.hip)
 SPLIT_MAX_R = 256   # the three-plane kernel: 96 A registers per lane at r = 128, 192 at r = 256 (eight waves per workgroup, two per SIMD)
 
 
 def split_topk_supported(r, k):
-    return 1 <= r <= SPLIT_MAX_R and 1 <= k <= 32
+    return 1 <= r <= SPLIT_MAX_R and 1 <= k <= SPLIT_MAX_K
 
 
 def half2_topk_supported(r, k):
@@ -111,7 +112,7 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     """Top-k item ids (int32) of user_embedding @ item_embedding^T per user, fused (no [m, n] matrix).
     fp32 tables: 'fp32' = fp32 MFMA (k <= 64, width <= 256, bit-equal to an fmaf chain); 'split' = the bf16 matrix cores with ALL
     24 significand bits of every factor (three exact bf16 planes per factor, six plane products each exact in the fp32
-    accumulator; ~1.9x the rate of the fp32 kernel, errors against fp64 at or below its; width <= 256 - 1.55x the fp32 kernel at 256: 171 against 110 TF -, k <= 32).
+    accumulator; ~1.9x the rate of the fp32 kernel, errors against fp64 at or below its; width <= 256 - 1.55x the fp32 kernel at 256: 171 against 110 TF -, k <= 40).
     'auto' (the default) takes 'split' where it applies and the job has SPLIT_MIN_SCORES scores or more, else 'fp32' - both keep
     the reference's fp32 operands whole (tf.matmul on fp32, matrix_factorization.py:236-248, 424-438).
     'half2' is an OPT-IN approximation, never chosen by 'auto': two fp16 planes under power-of-two scales = 22 bits of every
@@ -182,9 +183,12 @@ def predict_topk(user_embedding, item_embedding, k, clamp_negatives=False, retur
     idx = torch.empty(m, k, dtype=torch.int32, device=A.device)
     vals = torch.empty(m, k, dtype=torch.float32, device=A.device) if return_values else None
     if (arithmetic == 'split' and not split_topk_supported(r, k)) or (arithmetic == 'half2' and not half2_topk_supported(r, k)):
-        raise ValueError(f'the split kernels support widths <= 256 and k <= 32 (got {r}, {k})')
+        raise ValueError(f"the plane kernels support widths <= 256 and k <= {SPLIT_MAX_K} ('split') / 32 ('half2') (got {r}, {k})")
     if arithmetic == 'auto':
-        arithmetic = 'split' if m * n >= SPLIT_MIN_SCORES and split_topk_supported(r, k) else 'fp32'
+        # 32 < k <= 40 on tables of width <= 32: the fp32 kernel is the faster one (262144 x 100000, r = 32, k = 40: 43.9 against 38.1 TF;
+        # r = 64: 65 against 69, r = 96: 65 against 86, r = 128: 86 against 113, r = 256: 100 against 127)
+        planes = split_topk_supported(r, k) and not (k > 32 and r <= 32)
+        arithmetic = 'split' if m * n >= SPLIT_MIN_SCORES and planes else 'fp32'
         planes_optional = True    # 'auto' may fall back to the fp32 kernel (it needs no workspace) when memory is short
     else:
         planes_optional = False

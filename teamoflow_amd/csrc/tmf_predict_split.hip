@@ -51,12 +51,14 @@ typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_s;
 typedef __attribute__((address_space(1))) const void gbl_void_s;
 
-constexpr int SMAXK = 32, SMAXR = 256, SMAXR_HALF2 = 256;
-// Two shapes of workgroup.  WAVES = 4 (128 users, two workgroups per CU, k <= 22): the workgroups of a CU drift
+constexpr int SMAXK = 40 /* bf16 planes (round 5: two 4-wave workgroups' lists fit the LDS beside 8 pending entries per row up to 40) */, SMAXK_HALF2 = 32, SMAXR = 256, SMAXR_HALF2 = 256;
+// Two shapes of workgroup.  WAVES = 4 (128 users, two workgroups per CU): the workgroups of a CU drift
 // apart, so one multiplies while the other stands at its chunk barrier or files candidates - the two waves of a SIMD no longer
-// stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop, for k > 22
-// where two sets of lists do not fit the LDS (k > 22).  Pending entries per row: what the LDS leaves next to the lists.
-__host__ __device__ constexpr int split_cap(int waves, int k) { return waves == 4 ? (k <= 12 ? 16 : 8) : (k <= 16 ? 16 : 8); }
+// stall together.  WAVES = 8 (256 users, 3-slot ring, one workgroup per CU): half the item-table bytes per flop; it was the k > 22
+// shape until round 5 (two sets of lists did not fit the LDS beside rings of 64-wide k-chunks) and still is for the fp16 planes;
+// the bf16 planes now run k > 22 on 4-wave workgroups with 32-wide k-chunks (launch_predict_topk_split: +5 ... +26 %).
+// Pending entries per row: what the LDS leaves next to the lists.
+__host__ __device__ constexpr int split_cap(int waves, int k) { return waves == 4 ? (k <= 12 ? 16 : 8) : (k <= 16 ? 16 : 8); }   // never below 8: an overflowing tile is re-offered in groups of 8 columns
 // LDS ring slots: the two-plane chunks of the fp16 form are small enough for three of them beside two workgroups' lists
 __host__ __device__ constexpr int split_ring(int waves, bool half2) { return (waves == 4 && !half2) ? 2 : 3; }
 constexpr int kSplitRowsPad = 128;   // the item planes are padded to a multiple of this many rows (a multiple of every tile width)
@@ -560,9 +562,12 @@ static int launch_predict_topk_split_w(const float* A, const uint16_t* Bp, int64
     return check_launch(HALF2 ? "tmf_predict_topk_half2_f32" : "tmf_predict_topk_split_f32");
 }
 
-static int split_waves(int k) {   // TMF_SPLIT_WAVES=4|8 overrides (A/B runs)
-    static const int forced = [] { const char* e = getenv("TMF_SPLIT_WAVES"); return e ? atoi(e) : 0; }();
-    if (forced == 8 || k > 22) return 8;   // k <= 22: two workgroups' lists still fit beside their rings (80 KB each)
+static bool split_force8() {   // TMF_SPLIT_WAVES=8: the 8-wave instances for every k (A/B runs)
+    static const bool forced = [] { const char* e = getenv("TMF_SPLIT_WAVES"); return e && atoi(e) == 8; }();
+    return forced;
+}
+static int split_waves(int k) {
+    if (split_force8() || k > 22) return 8;   // k <= 22: two workgroups' lists still fit beside their rings of 64-wide k-chunks (80 KB each)
     return 4;
 }
 
@@ -574,6 +579,11 @@ static int launch_predict_topk_split(int ldp, int k, const float* A, const uint1
     return w4 ? launch_predict_topk_split_w<NJ, KS, NCH, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s)  \
               : launch_predict_topk_split_w<NJ, KS, NCH, 8, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s)
     if constexpr (HALF2) {   // 64 A registers at r = 128: 128-item tiles throughout, k-chunks of 32
+        if (!w4 && !split_force8()) {   // k > 22: 4-wave workgroups on 64-item tiles, like the bf16 planes below
+            if (ldp == 32) return launch_predict_topk_split_w<2, 2, 1, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
+            if (ldp == 64) return launch_predict_topk_split_w<2, 2, 2, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
+            if (ldp == 128) return launch_predict_topk_split_w<2, 2, 4, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
+        }
         if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
         if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
         if (ldp == 128) { TMF_SPLIT_GO(4, 2, 4); }
@@ -583,23 +593,34 @@ static int launch_predict_topk_split(int ldp, int k, const float* A, const uint1
         // LDS up to k = 32 beside the ring, so the shape that is tested is the one that runs.
         return launch_predict_topk_split_w<2, 4, 4, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
     } else {
+        // k > 22 (round 5): 4-wave workgroups as well, on k-chunks of 32 (64-item tiles, 12 KB ring slots) - two workgroups' lists fit
+        // the LDS up to k = 32, and the two workgroups of a CU drift apart again: in ONE 8-wave workgroup every wave that files or merges
+        // candidates holds the other seven at the chunk barrier.  262144 x 100000, 8-wave -> 4-wave instances, same box:
+        //   r = 128: k = 23 144 -> 164 TF, 25: 136 -> 156, 28: 124 -> 148, 32: 108 -> 133;  r = 256: k = 25 145 -> 152, 32: 128 -> 140;  r = 96, k = 32: 82 -> 103
+        // TMF_SPLIT_WAVES=8 brings the 8-wave instances back (A/B runs).
+        if (!w4 && !split_force8()) {
+            if (ldp == 32) return launch_predict_topk_split_w<2, 2, 1, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
+            if (ldp == 64) return launch_predict_topk_split_w<2, 2, 2, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
+            if (ldp == 128) return launch_predict_topk_split_w<2, 2, 4, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
+            return launch_predict_topk_split_w<2, 2, 8, 4, HALF2>(A, Bp, m, n, n_pad, K, lda, k, clamp, out_idx, out_val, item_scale, s);
+        }
         if (ldp == 32) { TMF_SPLIT_GO(4, 2, 1); }
         if (ldp == 64) { TMF_SPLIT_GO(4, 2, 2); }
         if (ldp == 128) { TMF_SPLIT_GO(2, 4, 2); }
-        TMF_SPLIT_GO(2, 4, 4);   // r <= 256 (round 5): 192 A registers - eight waves per workgroup, two per SIMD, 256 VGPRs each
+        TMF_SPLIT_GO(2, 4, 4);   // r <= 256 (round 5): 192 A registers, two waves per SIMD, 256 VGPRs each
     }
 #undef TMF_SPLIT_GO
 }
 
 static int check_split_args(const char* what, const float* A, const float* B, int32_t* out_idx, int64_t m, int64_t n, int r,
-                            int64_t lda, int64_t ldb, int k, void* workspace, size_t workspace_bytes, size_t need, int max_r) {
+                            int64_t lda, int64_t ldb, int k, void* workspace, size_t workspace_bytes, size_t need, int max_r, int max_k) {
     TMF_REQUIRE(A && B && out_idx && m > 0 && n > 0 && r > 0, "%s: bad arguments", what);
     TMF_REQUIRE(lda >= r && ldb >= r && (lda % 4 == 0) && ((uintptr_t)A % 16 == 0),
                 "%s: the user table must be 16-byte aligned with ld %% 4 == 0", what);
     TMF_REQUIRE(k >= 1 && k <= n, "%s: k=%d must be in [1, n=%lld]", what, k, (long long)n);
     TMF_REQUIRE(n < ((int64_t)1 << 31), "%s: too many items", what);
-    if (r > max_r || k > SMAXK) {
-        set_error("%s: supports k <= %d and n_components <= %d (got k=%d, r=%d)", what, SMAXK, max_r, k, r);
+    if (r > max_r || k > max_k) {
+        set_error("%s: supports k <= %d and n_components <= %d (got k=%d, r=%d)", what, max_k, max_r, k, r);
         return TMF_E_UNSUPPORTED;
     }
     TMF_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
@@ -619,7 +640,7 @@ extern "C" size_t tmf_predict_topk_split_workspace_bytes(int64_t n, int r) {
 }
 
 extern "C" int tmf_predict_topk_half2_supported(int r, int k) {
-    return r >= 1 && r <= tmf::SMAXR_HALF2 && k >= 1 && k <= tmf::SMAXK;
+    return r >= 1 && r <= tmf::SMAXR_HALF2 && k >= 1 && k <= tmf::SMAXK_HALF2;
 }
 
 extern "C" size_t tmf_predict_topk_half2_workspace_bytes(int64_t n, int r) {
@@ -632,7 +653,7 @@ extern "C" int tmf_predict_topk_split_f32(const float* A, const float* B, int64_
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return TMF_OK;
     if (int rc = tmf::check_split_args("predict_topk_split", A, B, out_idx, m, n, r, lda, ldb, k, workspace, workspace_bytes,
-                                       tmf_predict_topk_split_workspace_bytes(n, r), tmf::SMAXR))
+                                       tmf_predict_topk_split_workspace_bytes(n, r), tmf::SMAXR, tmf::SMAXK))
         return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ldp = tmf::split_ldp(r);
@@ -653,7 +674,7 @@ extern "C" int tmf_predict_topk_half2_f32(const float* A, const float* B, int64_
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return TMF_OK;
     if (int rc = tmf::check_split_args("predict_topk_half2", A, B, out_idx, m, n, r, lda, ldb, k, workspace, workspace_bytes,
-                                       tmf_predict_topk_half2_workspace_bytes(n, r), tmf::SMAXR_HALF2))
+                                       tmf_predict_topk_half2_workspace_bytes(n, r), tmf::SMAXR_HALF2, tmf::SMAXK_HALF2))
         return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ldp = tmf::split_ldp(r);

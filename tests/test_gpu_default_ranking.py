@@ -70,7 +70,7 @@ def test_default_ranking_equals_tf_top_k_on_the_golden_tables(ops, monkeypatch, 
 
 
 def test_auto_never_takes_the_two_plane_form(ops, monkeypatch):
-    """From 2^26 scores on 'auto' runs the three-plane kernel (width <= 256, k <= 32) or the fp32 MFMA - never half2, whatever
+    """From 2^26 scores on 'auto' runs the three-plane kernel (width <= 256, k <= 40) or the fp32 MFMA - never half2, whatever
     the range of the item rows; half2 still answers when asked for by name."""
     from teamoflow_amd import _lib
     lib = _lib.get()
@@ -87,9 +87,14 @@ def test_auto_never_takes_the_two_plane_form(ops, monkeypatch):
     assert calls == ['tmf_predict_topk_split_f32']
     assert float((idx.long() == want).all(1).float().mean()) > 0.995
     calls.clear()
-    ops.predict_topk(U, V, 48)                                     # beyond the plane kernels' k: the fp32 MFMA
+    ops.predict_topk(U, V, 41)                                     # beyond the plane kernels' k: the fp32 MFMA
     ops.predict_topk(U[:100], V, 10)                               # a small job: the fp32 MFMA
-    assert calls == ['tmf_predict_topk_f32', 'tmf_predict_topk_f32']
+    ops.predict_topk(U, V, 40)                                     # the plane kernel's last k (round 5: 32 -> 40)
+    assert calls == ['tmf_predict_topk_f32', 'tmf_predict_topk_f32', 'tmf_predict_topk_split_f32']
+    calls.clear()
+    ops.predict_topk(U[:, :32].contiguous(), V[:, :32].contiguous(), 40)   # narrow tables beyond k = 32: the fp32 kernel is the faster one
+    ops.predict_topk(U[:, :32].contiguous(), V[:, :32].contiguous(), 32)
+    assert calls == ['tmf_predict_topk_f32', 'tmf_predict_topk_split_f32']
     calls.clear()
     ops.predict_topk(U, V, 10, arithmetic='half2')
     assert calls == ['tmf_predict_topk_half2_f32']

@@ -34,7 +34,7 @@ def test_exact_on_small_integer_factors(ops, seed, arith):
     m = int(rng.integers(1, 600))
     n = int(rng.choice([1, 7, 128, 129, 1000, 4097, 16384, 20011, 33000, 40000]))
     r = int(rng.choice([1, 3, 8, 31, 32, 33, 50, 64, 65, 100, 127, 128, 129, 192, 255, 256]))
-    k = int(min(n, rng.choice([1, 2, 5, 10, 16, 17, 32])))
+    k = int(min(n, rng.choice([1, 2, 5, 10, 16, 17, 32] if arith == 'half2' else [1, 2, 5, 10, 16, 17, 23, 32, 33, 39, 40])))
     span = int(rng.choice([1, 2, 4]))
     U = rng.integers(-span, span + 1, (m, r)).astype(np.float32)
     V = rng.integers(-span, span + 1, (n, r)).astype(np.float32)
@@ -171,7 +171,7 @@ def test_deferred_merges_and_overflow(ops, arith):
     U = np.eye(r, dtype=np.float32)[np.arange(m) % r]
     U[7] = 0
     sc = U @ V.T
-    for k in (1, 10, 32):
+    for k in (1, 10, 32) + ((33, 40) if arith == 'split' else ()):
         for clamp in (False, True):
             vals, got = ops.predict_topk(torch.tensor(U), torch.tensor(V), k, clamp_negatives=clamp, return_values=True, arithmetic=arith)
             ref = expected(sc, k, clamp)
@@ -189,13 +189,16 @@ def test_limits_and_errors(ops):
     from teamoflow_amd import _lib
     lib = _lib.get()
     assert lib.tmf_predict_topk_split_supported(256, 32) == 1 and lib.tmf_predict_topk_split_supported(257, 10) == 0
-    assert lib.tmf_predict_topk_split_supported(64, 33) == 0 and lib.tmf_predict_topk_split_workspace_bytes(1000, 257) == 0
+    assert lib.tmf_predict_topk_split_supported(64, 40) == 1 and lib.tmf_predict_topk_split_supported(64, 41) == 0
+    assert lib.tmf_predict_topk_half2_supported(64, 33) == 0 and lib.tmf_predict_topk_split_workspace_bytes(1000, 257) == 0
     assert lib.tmf_predict_topk_split_workspace_bytes(1000, 129) == 3 * 1024 * 256 * 2
     assert lib.tmf_predict_topk_split_workspace_bytes(1000, 100) == 3 * 1024 * 128 * 2
     with pytest.raises(ValueError):
         ops.predict_topk(torch.ones(4, 300), torch.ones(9, 300), 2, arithmetic='split')
     with pytest.raises(ValueError):
-        ops.predict_topk(torch.ones(4, 8), torch.ones(99, 8), 40, arithmetic='split')
+        ops.predict_topk(torch.ones(4, 8), torch.ones(99, 8), 41, arithmetic='split')
+    with pytest.raises(ValueError):
+        ops.predict_topk(torch.ones(4, 8), torch.ones(99, 8), 33, arithmetic='half2')
     x = torch.ones(8, 8, device='cuda')
     out = torch.empty(8, 2, dtype=torch.int32, device='cuda')
     ws = torch.empty(64, dtype=torch.uint8, device='cuda')

@@ -259,7 +259,7 @@ def test_half2_range_guard_on_cpu():
     assert _ops.half2_range_ok(V)
     V[9, 0] = float('inf')
     assert not _ops.half2_range_ok(V)
-    assert _ops.split_topk_supported(256, 32) and not _ops.split_topk_supported(257, 1) and not _ops.split_topk_supported(64, 33)
+    assert _ops.split_topk_supported(256, 32) and not _ops.split_topk_supported(257, 1) and _ops.split_topk_supported(64, 40) and not _ops.split_topk_supported(64, 41)
     assert _ops.half2_topk_supported(256, 32) and not _ops.half2_topk_supported(257, 1) and not _ops.half2_topk_supported(8, 33)
 
 
